@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""bench.py -- images/sec of one full WGAN-GP + blur training step (D-step with gradient penalty + G-step,
+Adam on both), BASELINE.json's metric, on synthetic CelebA-shaped batches.
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+N=1 workload = BASELINE.json configs[1]: CelebA 64x64 RGB, batch 256, blur sigma schedule on
+(BlurDecayController(max_value=5) -> 31 taps), 64-arch (build-side definition).
+N>1 = configs[2]: the same per-GPU work, batch 256 x N sharded data-parallel, RCCL SUM all-reduce of the
+critic and generator gradients ("weak" scaling).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_MFMA_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32-input MFMA peak
+PEAK_HBM_GBS = 8000.0
+CONV_GFLOP_PER_IMAGE = {"celeba64": 3.908, "celeba128": 4.769, "mnist": 0.659}
+
+
+def build_gan(arch, B, world, sigma):
+    import blurred_gan_amd as bg
+    from blurred_gan_amd import models, dist
+    bg.set_seed(123123)                                   # demo_celeba.py:132; every rank starts from identical weights
+    gen, disc = models.DCGANGenerator(arch=arch), models.DCGANDiscriminator(arch=arch)
+    hp = bg.BlurredWGANGP.HyperParameters(initial_blur_std=sigma, batch_size=B, global_batch_size=B * world)
+    gan = bg.BlurredWGANGP(gen, disc, hp, bg.TrainingConfig(log_dir="/tmp/bg_bench_logs"), sync_metrics=False)
+    gan._rng_seed = 123123 + dist.rank()
+    return gan
+
+
+def cpu_baseline(arch, sample_batch, seconds_budget=25.0):
+    """The oracle's torch-CPU port of the same step, timed on this box's host cores (reported, not a target)."""
+    from oracle.torch_ref import TorchTrainer
+    from oracle import models as OM
+    torch.manual_seed(0)
+    tr = TorchTrainer(arch, seed=0, std=5.0, hp=dict(global_batch_size=sample_batch))
+    gen = torch.Generator().manual_seed(0)
+    H, W, C = OM.image_shape(arch)
+    reals = torch.rand(sample_batch, H, W, C, generator=gen) * 2 - 1
+    t0 = time.time()
+    tr.train_on_batch(reals, tr.draw(sample_batch, gen))         # warm-up (oneDNN primitive creation)
+    warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while True:
+        tr.train_on_batch(reals, tr.draw(sample_batch, gen))
+        n += 1
+        if time.time() - t0 + warm > seconds_budget or n >= 5:
+            break
+    dt = time.time() - t0
+    return {"value": round(sample_batch * n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} step(s) of batch {sample_batch} of the same {arch} step (oracle/torch_ref.py, torch-CPU fp32, "
+                      f"autograd double backward for the penalty)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--arch", default="celeba64", choices=["celeba64", "celeba128", "mnist"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256; 128 for celeba128; 64 for mnist)")
+    ap.add_argument("--sigma", type=float, default=5.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=16)
+    args = ap.parse_args()
+
+    from blurred_gan_amd import dist, ops, callbacks
+    world = dist.init_from_env()
+    assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(dist.local_rank())
+    B = args.batch or {"celeba64": 256, "celeba128": 128, "mnist": 64}[args.arch]
+    gan = build_gan(args.arch, B, world, args.sigma)
+    from blurred_gan_amd.models import IMAGE_SHAPE
+    H, W, C = IMAGE_SHAPE[args.arch]
+    g = torch.Generator(device="cuda").manual_seed(123123 + dist.rank())
+    reals = torch.rand(B, H, W, C, device="cuda", generator=g) * 2 - 1
+    total_examples = 202599 * 10                                   # CelebA x 10 epochs (demo_celeba.py:135,226)
+    ctl = callbacks.BlurDecayController(total_n_training_examples=total_examples, max_value=args.sigma)
+    ctl.set_model(gan)
+
+    def step():
+        ctl.on_batch_begin(0, {})
+        gan.train_on_batch(reals)
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
+    if world > 1:
+        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tmax.item())
+    value = B * world * args.steps / dt
+
+    # ---- per-kernel HIP-event timing on the launch stream (separate, un-timed steps)
+    roof = None
+    kern = {}
+    if not args.no_profile:
+        ops.prof_reset()
+        ops.prof_enable(True)
+        nprof = 2
+        for _ in range(nprof):
+            step()
+        torch.cuda.synchronize()
+        recs = ops.prof_records()
+        ops.prof_enable(False)
+        ops.prof_reset()
+        for name, ms, fl, by in recs:
+            k = kern.setdefault(name, [0, 0.0, 0.0, 0.0])
+            k[0] += 1; k[1] += ms; k[2] += fl; k[3] += by
+        mfma = {n: k for n, k in kern.items() if n.startswith("conv_igemm") or n.startswith("conv_wgrad_mfma")}
+        if mfma:
+            dom = max(mfma, key=lambda n: mfma[n][1])
+            cnt, ms, fl, _ = mfma[dom]
+            ach = fl / (ms * 1e-3) / 1e12
+            all_ms = sum(k[1] for k in mfma.values())
+            all_fl = sum(k[2] for k in mfma.values())
+            roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "launches_per_step": cnt // nprof, "avg_launch_ms": round(ms / cnt, 5),
+                    "all_mfma_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 3),
+                                         "frac": round(all_fl / (all_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
+                                         "ms_per_step": round(all_ms / nprof, 4)},
+                    "step_conv_frac": round(CONV_GFLOP_PER_IMAGE[args.arch] * value / world / 1e3 / PEAK_MFMA_F32_TFLOPS, 4)}
+
+    if dist.rank() == 0:
+        out = {"metric": "images/sec (G+D+GP step)", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"{args.arch} {H}x{W}x{C} batch {B}/GPU, blur sigma {args.sigma} "
+                                      f"({ops.blur_policy(float(gan.std), H, W)[2]} taps), D-step+GP+G-step+Adam",
+                          "global_batch": B * world, "parallelism": f"dp{world}"}}
+        if roof is not None:
+            out["roofline"] = roof
+        if kern:
+            top = sorted(kern.items(), key=lambda kv: -kv[1][1])[:12]
+            out["kernels_ms_per_step"] = {n: round(k[1] / 2, 4) for n, k in top}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_sample_batch)
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+
+
+if __name__ == "__main__":
+    main()

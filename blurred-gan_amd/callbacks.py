@@ -1,0 +1,183 @@
+"""Mirror of reference callbacks.py: the Keras-callback controllers of the blur sigma and the periodic
+host-side hooks.  Same class names, constructor arguments and hook methods; pure host code."""
+from __future__ import annotations
+
+import os
+from typing import Dict
+
+import numpy as np
+
+
+class Callback:
+    """tf.keras.callbacks.Callback stand-in: ``self.model`` is set by ``fit``."""
+
+    def __init__(self):
+        self.model = None
+
+    def set_model(self, model):
+        self.model = model
+
+
+class ExponentialDecay:
+    """tf.keras.optimizers.schedules.ExponentialDecay(staircase=False): init * rate ** (step / decay_steps),
+    evaluated in float32 like TF."""
+
+    def __init__(self, initial_learning_rate, decay_steps, decay_rate, staircase=False):
+        self.initial, self.decay_steps, self.rate, self.staircase = float(initial_learning_rate), float(decay_steps), float(decay_rate), staircase
+
+    def __call__(self, step):
+        p = np.float32(float(step)) / np.float32(self.decay_steps)
+        if self.staircase:
+            p = np.floor(p)
+        return float(np.float32(self.initial) * np.power(np.float32(self.rate), np.float32(p)))
+
+
+class ExecuteEveryNExamplesCallback(Callback):
+    """callbacks.py:12-43."""
+
+    def __init__(self, n: int, starting_from: int = 0):
+        super().__init__()
+        self.period = n
+        self.num_invocations = 0
+        self.samples_seen = 0
+        self.starting_from = starting_from
+
+    def on_batch_end(self, batch, logs: Dict):
+        batch_size = logs["size"]
+        self.samples_seen += batch_size
+        i = (self.samples_seen - self.starting_from) // self.period
+        if self.samples_seen < self.starting_from:
+            return
+        if i >= self.num_invocations:
+            self.num_invocations += 1
+            self.function(batch, logs)
+
+    def function(self, batch, logs):
+        raise NotImplementedError("Implement the 'function' inside your class!")
+
+
+class BlurDecayController(Callback):
+    """callbacks.py:45-62.  Quirk Q5 reproduced: the schedule is evaluated at the BATCH index while
+    ``decay_steps`` counts EXAMPLES; ``min_value`` is accepted and ignored, as in the reference."""
+
+    def __init__(self, total_n_training_examples: int, max_value: float = 23.5, min_value=0.01):
+        super().__init__()
+        self.schedule = ExponentialDecay(float(max_value), decay_steps=total_n_training_examples / 10, decay_rate=0.96,
+                                         staircase=False)
+
+    def on_batch_begin(self, batch, logs):
+        value = self.schedule(int(self.model.n_batches))
+        self.model.std.assign(value)
+
+
+class AdaptiveBlurController(Callback):
+    """callbacks.py:65-135 (the reference only *logs* "would_modify"; the assign is commented out at :102-103)."""
+
+    def __init__(self, smoothing=0.99, warmup_n_batches=100, threshold=0.05, min_value=0.01, max_value=23.5):
+        super().__init__()
+        self.smoothing = smoothing
+        self.warmup_n_batches = warmup_n_batches
+        self.score_ratio = 0.5
+        self.threshold = threshold
+        self._last_modification_step = 0
+        self.delay_between_modifications = 100
+        self.std = float(max_value)
+        self.min_value = min_value
+
+    def on_train_begin(self, logs=None):
+        self.model.std.assign(self.std)
+
+    def gan_problem_is_stable(self) -> bool:
+        return 0.5 - self.threshold <= self.score_ratio <= 0.5 + self.threshold
+
+    def decrease_blur_std(self, batch: int) -> None:
+        just_modified = batch - self._last_modification_step < self.delay_between_modifications
+        with self.model.summary_writer.as_default() as w:
+            if not just_modified:
+                self.std = self.smoothing * self.std
+                w.scalar("blur_controller/would_modify", 1)
+                self._last_modification_step = batch
+            else:
+                w.scalar("blur_controller/would_modify", 0)
+
+    def on_batch_end(self, batch, logs):
+        fake_scores, real_scores = logs["fake_scores"], logs["real_scores"]
+        ratio = fake_scores / (real_scores + fake_scores)
+        self.score_ratio = self.smoothing * self.score_ratio + (1 - self.smoothing) * ratio
+        if batch < self.warmup_n_batches:
+            return
+        with self.model.summary_writer.as_default() as w:
+            w.scalar("blur_controller/ratio", ratio)
+            w.scalar("blur_controller/smoothed_ratio", self.score_ratio)
+            w.scalar("blur_controller/stable", int(self.gan_problem_is_stable()))
+        if self.gan_problem_is_stable():
+            self.decrease_blur_std(batch)
+        if self.std < self.min_value:
+            print("Reached the minimum STD. Training is complete.")
+            self.model.stop_training = True
+
+
+class GenerateSampleGridCallback(ExecuteEveryNExamplesCallback):
+    """callbacks.py:209-236: an 8x8 grid of samples from fixed latents, written as PNG (PIL, no matplotlib)."""
+
+    def __init__(self, log_dir: str, show_blurred_samples=True, every_n_examples=1000, also_save_files=True):
+        self.log_dir = log_dir
+        self.show_blurred_samples = show_blurred_samples
+        super().__init__(n=every_n_examples)
+        self.also_save_files = also_save_files
+        self.latents = None
+
+    def function(self, batch, logs):
+        self.make_grid()
+
+    def on_train_begin(self, logs: Dict):
+        rng = np.random.default_rng(0)
+        self.latents = rng.uniform(size=(64, self.model.generator.input_shape[-1])).astype(np.float32)
+
+    def make_grid(self, *args):
+        from .utils import normalize_images
+        samples = self.model.generate_samples(self.latents, training=False)
+        if self.show_blurred_samples and hasattr(self.model, "blur"):
+            samples = self.model.blur(samples)
+        s = normalize_images(samples).clamp(0, 1).cpu().numpy()
+        n, h, w, c = s.shape
+        grid = s[:64].reshape(8, 8, h, w, c).transpose(0, 2, 1, 3, 4).reshape(8 * h, 8 * w, c)
+        if self.also_save_files:
+            from PIL import Image
+            os.makedirs(self.log_dir, exist_ok=True)
+            img = (grid * 255).astype(np.uint8)
+            Image.fromarray(img[..., 0] if c == 1 else img).save(os.path.join(self.log_dir, f"samples_grid_{self.samples_seen:06}.png"))
+        return grid
+
+
+class SaveModelCallback(ExecuteEveryNExamplesCallback):
+    """callbacks.py:239-246."""
+
+    def __init__(self, checkpoint_manager, n: int = 10_000):
+        super().__init__(n=n)
+        self.manager = checkpoint_manager
+
+    def function(self, batch, logs):
+        self.manager.save(self.samples_seen)
+
+
+class LogMetricsCallback(ExecuteEveryNExamplesCallback):
+    """callbacks.py:249-268."""
+
+    def __init__(self, every_n_examples: int = 100):
+        super().__init__(n=every_n_examples)
+
+    def on_train_begin(self, logs):
+        self.samples_seen = self.model.n_img.numpy()
+
+    def function(self, batch: int, logs: Dict):
+        self.write_metric_summaries(logs, prefix="batch_")
+
+    def on_epoch_end(self, epoch: int, logs: Dict):
+        self.write_metric_summaries(logs, prefix="epoch_")
+
+    def write_metric_summaries(self, logs: Dict, prefix="", flush=False):
+        with self.model.summary_writer.as_default() as w:
+            for name, value in logs.items():
+                if name not in ("batch", "size"):
+                    w.scalar(f"{prefix}{name}", value, step=int(self.model.n_img))

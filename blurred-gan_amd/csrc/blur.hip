@@ -1,0 +1,160 @@
+// Separable Gaussian blur, NHWC float32 -- replaces the two tf.nn.depthwise_conv2d calls of
+// reference gaussian_blur.py:116-130 (pass 1 along H, pass 2 along W, SAME zero padding) and the
+// host-side sigma policy of gaussian_blur.py:15-88.
+//
+// HBM-bound op: algorithmic traffic is 8*H*W*C bytes per image (read once, write once).
+//   blur_fused_kernel  one workgroup per image, whole image resident in LDS, both passes fused
+//                      (traffic == algorithmic); used when 2 images fit in 160 KiB of LDS.
+//   blur_pass_kernel   generic one-axis pass through L1/L2 with a scratch image in HBM
+//                      (traffic 2x algorithmic); any size / tap count.
+#include "common.h"
+#include <cmath>
+
+namespace {
+
+constexpr int kBlurThreads = 256;
+
+__global__ __launch_bounds__(kBlurThreads) void blur_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                  int H, int W, int C,
+                                                                  const float* __restrict__ taps, int T) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int WC = W * C, n = H * WC, half = T >> 1;
+  float* s0 = lds;
+  float* s1 = lds + ((n + 3) & ~3);
+  const float* xi = x + (size_t)blockIdx.x * n;
+  float* yi = y + (size_t)blockIdx.x * n;
+  const int tid = threadIdx.x;
+  if ((n & 3) == 0) {
+    for (int e = tid * 4; e < n; e += kBlurThreads * 4) *reinterpret_cast<float4*>(s0 + e) = *reinterpret_cast<const float4*>(xi + e);
+  } else {
+    for (int e = tid; e < n; e += kBlurThreads) s0[e] = xi[e];
+  }
+  __syncthreads();
+  // pass 1: along H (gaussian_blur.py:116-122)
+  for (int e = tid; e < n; e += kBlurThreads) {
+    const int h = e / WC;
+    const int jlo = max(0, half - h), jhi = min(T, H + half - h);
+    const float* col = s0 + e - half * WC;
+    float acc = 0.f;
+    for (int j = jlo; j < jhi; ++j) acc = fmaf(taps[j], col[j * WC], acc);
+    s1[e] = acc;
+  }
+  __syncthreads();
+  // pass 2: along W (gaussian_blur.py:124-130)
+  for (int e = tid; e < n; e += kBlurThreads) {
+    const int h = e / WC;
+    const int w = (e - h * WC) / C;
+    const int jlo = max(0, half - w), jhi = min(T, W + half - w);
+    const float* row = s1 + e - half * C;
+    float acc = 0.f;
+    for (int j = jlo; j < jhi; ++j) acc = fmaf(taps[j], row[j * C], acc);
+    yi[e] = acc;
+  }
+}
+
+// AXIS 0: along H (neighbour stride W*C); AXIS 1: along W (neighbour stride C).
+template <int AXIS>
+__global__ __launch_bounds__(kBlurThreads) void blur_pass_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                 size_t total, int H, int W, int C,
+                                                                 const float* __restrict__ taps, int T) {
+  const int WC = W * C, half = T >> 1;
+  for (size_t e = (size_t)blockIdx.x * kBlurThreads + threadIdx.x; e < total; e += (size_t)gridDim.x * kBlurThreads) {
+    const size_t row = e / WC;                 // b*H + h
+    const int h = (int)(row % H);
+    const int w = (int)(e - row * WC) / C;
+    const int pos = AXIS == 0 ? h : w;
+    const int len = AXIS == 0 ? H : W;
+    const int st = AXIS == 0 ? WC : C;
+    const int jlo = max(0, half - pos), jhi = min(T, len + half - pos);
+    const float* src = x + e - (size_t)half * st;   // only dereferenced for j in [jlo, jhi)
+    float acc = 0.f;
+    for (int j = jlo; j < jhi; ++j) acc = fmaf(taps[j], src[(size_t)j * st], acc);
+    y[e] = acc;
+  }
+}
+
+size_t fused_lds_bytes(int H, int W, int C) { return 2 * (size_t)(((H * W * C) + 3) & ~3) * sizeof(float); }
+constexpr size_t kFusedLdsCap = 150 * 1024;
+
+}  // namespace
+
+extern "C" {
+
+int bg_blur_policy(float sigma, int H, int W, float* kernel_size, float* sigma_eff, int* n_taps) {
+  BG_REQUIRE(H > 0 && W > 0, BG_ERR_BAD_SHAPE, "bg_blur_policy: H=%d W=%d", H, W);
+  // gaussian_blur.py:21-26 "(6*std)*2//2+1", :67 clip to [3, max(h,w)], :29-31,71-72 sigma re-derived; float32.
+  const float full = (float)(H > W ? H : W);
+  float ks = floorf(((6.0f * sigma) * 2.0f) / 2.0f) + 1.0f;
+  ks = fminf(fmaxf(ks, 3.0f), full);
+  float s = (ks - 1.0f) / 6.0f;
+  s = fmaxf(s, 0.01f);
+  if (kernel_size) *kernel_size = ks;
+  if (sigma_eff) *sigma_eff = s;
+  if (n_taps) *n_taps = 2 * (int)floorf(ks / 2.0f) + 1;   // gaussian_blur.py:84 range(-(ks//2), ks//2+1)
+  return BG_OK;
+}
+
+int bg_gauss_kernel_1d(float sigma_eff, float kernel_size, float* taps_host, int cap, int* n_taps) {
+  BG_REQUIRE(taps_host != nullptr, BG_ERR_NULL, "bg_gauss_kernel_1d: taps_host is NULL");
+  BG_REQUIRE(sigma_eff > 0.f && kernel_size >= 1.f, BG_ERR_BAD_SHAPE, "bg_gauss_kernel_1d: sigma=%g ks=%g", sigma_eff, kernel_size);
+  const int half = (int)floorf(kernel_size / 2.0f);
+  const int T = 2 * half + 1;
+  BG_REQUIRE(T <= cap, BG_ERR_WORKSPACE, "bg_gauss_kernel_1d: need %d taps, capacity %d", T, cap);
+  // gaussian_blur.py:85-87, float32 arithmetic
+  const float denom = sqrtf(2.0f * 3.14159265358979323846f) * sigma_eff;
+  const float two_s2 = 2.0f * (sigma_eff * sigma_eff);
+  float sum = 0.f;
+  for (int j = 0; j < T; ++j) {
+    const float xv = (float)(j - half);
+    taps_host[j] = expf(-((xv * xv) / two_s2)) / denom;
+    sum += taps_host[j];
+  }
+  for (int j = 0; j < T; ++j) taps_host[j] /= sum;
+  if (n_taps) *n_taps = T;
+  return BG_OK;
+}
+
+size_t bg_blur_workspace_bytes(int B, int H, int W, int C, int n_taps) {
+  (void)n_taps;
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
+  if (fused_lds_bytes(H, W, C) <= kFusedLdsCap) return 0;
+  return (size_t)B * H * W * C * sizeof(float);
+}
+
+int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const float* taps_d, int n_taps,
+                     float* tmp_d, void* stream) {
+  BG_REQUIRE(x && y && taps_d, BG_ERR_NULL, "bg_blur_nhwc_f32: null pointer");
+  BG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_blur_nhwc_f32: B=%d H=%d W=%d C=%d", B, H, W, C);
+  BG_REQUIRE(n_taps >= 1 && (n_taps & 1), BG_ERR_BAD_SHAPE, "bg_blur_nhwc_f32: tap count %d must be odd", n_taps);
+  BG_REQUIRE(bg::aligned16(x) && bg::aligned16(y), BG_ERR_BAD_ALIGNMENT, "bg_blur_nhwc_f32: x/y must be 16-byte aligned");
+  const size_t total = (size_t)B * H * W * C;
+  const double flops = 4.0 * n_taps * (double)total, bytes = 8.0 * (double)total;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const size_t lds = fused_lds_bytes(H, W, C);
+  if (lds <= kFusedLdsCap) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_fused_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsCap);
+      if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "bg_blur_nhwc_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr_set = true;
+    }
+    bg::Launch L(stream, "blur_fused", flops, bytes);
+    hipLaunchKernelGGL(blur_fused_kernel, dim3(B), dim3(kBlurThreads), lds, s, x, y, H, W, C, taps_d, n_taps);
+    return L.done("blur_fused_kernel");
+  }
+  BG_REQUIRE(tmp_d != nullptr, BG_ERR_WORKSPACE, "bg_blur_nhwc_f32: image of %zu bytes needs tmp_d (see bg_blur_workspace_bytes)",
+             (size_t)H * W * C * 4);
+  const unsigned grid = (unsigned)std::min<size_t>(bg::cdiv(total, kBlurThreads), 256 * 16);
+  {
+    bg::Launch L(stream, "blur_pass_h", flops / 2, bytes);
+    hipLaunchKernelGGL(blur_pass_kernel<0>, dim3(grid), dim3(kBlurThreads), 0, s, x, tmp_d, total, H, W, C, taps_d, n_taps);
+    int rc = L.done("blur_pass_kernel<H>");
+    if (rc) return rc;
+  }
+  bg::Launch L(stream, "blur_pass_w", flops / 2, bytes);
+  hipLaunchKernelGGL(blur_pass_kernel<1>, dim3(grid), dim3(kBlurThreads), 0, s, tmp_d, y, total, H, W, C, taps_d, n_taps);
+  return L.done("blur_pass_kernel<W>");
+}
+
+}  // extern "C"

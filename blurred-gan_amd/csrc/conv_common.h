@@ -1,0 +1,137 @@
+// Gather-GEMM description shared by the conv forward / data-gradient kernels.
+//
+// Both TF ops reduce to   C[m, n] = sum_{tap, c}  A[src(m, tap), c] * Wt[wi(tap)][n][c]
+// with m running over an "anchor" grid (b, a, bx) of one phase:
+//   forward  (Conv2D, demo_celeba.py:99-119):  src = (a*s + kh - pt, bx*s + kw - pl), dst = (a, bx), 1 phase
+//   data-grad / Conv2DTranspose forward (demo_celeba.py:62-87): sub-pixel decomposition, s*s phases,
+//            phase (py,px): dst = (a*s + py, bx*s + px); only taps with (py + pt - kh) % s == 0 contribute,
+//            src = (a + (py+pt-kh)/s, bx + (px+pl-kw)/s)  -- no zero-insertion, no wasted MACs.
+// TF 'SAME': out = ceil(in/s), pad_total = max((out-1)s + k - in, 0), pad_before = pad_total/2.
+#pragma once
+#include "common.h"
+
+namespace bg {
+
+constexpr int kMaxTaps = 25;
+constexpr int kMaxPhases = 4;
+
+struct GatherPhase {
+  int Ha, Wa;          // anchor grid of this phase
+  int py, px;          // destination offset
+  int ntaps;
+  int tap[kMaxTaps];   // (dy+64) | (dx+64)<<8 | wi<<16
+};
+
+struct GatherParams {
+  const float* A;      // [B][Hs][Ws][Ck]
+  const float* Wt;     // [taps][N][Ck]
+  float* C;            // [B][Hd][Wd][N]
+  int B, Hs, Ws, Ck;
+  int Hd, Wd, N;
+  int ss, ds;          // source / destination stride multipliers
+  int nphase;
+  // epilogue
+  int epi_mode;
+  const float* bias;
+  const float* ref;
+  const uint8_t* keep;
+  float alpha, scale;
+  GatherPhase ph[kMaxPhases];
+};
+
+__host__ __device__ inline int tap_dy(int t) { return (t & 0xff) - 64; }
+__host__ __device__ inline int tap_dx(int t) { return ((t >> 8) & 0xff) - 64; }
+__host__ __device__ inline int tap_wi(int t) { return t >> 16; }
+inline int pack_tap(int dy, int dx, int wi) { return (dy + 64) | ((dx + 64) << 8) | (wi << 16); }
+
+inline void same_pads(int n, int k, int s, int* out, int* before) {
+  const int o = (n + s - 1) / s;
+  int tot = (o - 1) * s + k - n;
+  if (tot < 0) tot = 0;
+  *out = o;
+  *before = tot / 2;
+}
+
+// H, W, Cin: conv input side; Cout: conv output side.
+inline int make_fwd_params(GatherParams& p, int B, int H, int W, int Cin, int Cout, int k, int s) {
+  int Ho, Wo, pt, pl;
+  same_pads(H, k, s, &Ho, &pt);
+  same_pads(W, k, s, &Wo, &pl);
+  p.B = B; p.Hs = H; p.Ws = W; p.Ck = Cin;
+  p.Hd = Ho; p.Wd = Wo; p.N = Cout;
+  p.ss = s; p.ds = 1; p.nphase = 1;
+  GatherPhase& g = p.ph[0];
+  g.Ha = Ho; g.Wa = Wo; g.py = 0; g.px = 0; g.ntaps = 0;
+  for (int kh = 0; kh < k; ++kh)
+    for (int kw = 0; kw < k; ++kw) g.tap[g.ntaps++] = pack_tap(kh - pt, kw - pl, kh * k + kw);
+  return 0;
+}
+
+inline int make_bwd_data_params(GatherParams& p, int B, int H, int W, int Cin, int Cout, int k, int s) {
+  int Ho, Wo, pt, pl;
+  same_pads(H, k, s, &Ho, &pt);
+  same_pads(W, k, s, &Wo, &pl);
+  p.B = B; p.Hs = Ho; p.Ws = Wo; p.Ck = Cout;
+  p.Hd = H; p.Wd = W; p.N = Cin;
+  p.ss = 1; p.ds = s; p.nphase = 0;
+  for (int py = 0; py < s; ++py)
+    for (int px = 0; px < s; ++px) {
+      GatherPhase& g = p.ph[p.nphase++];
+      g.py = py; g.px = px;
+      g.Ha = (H - py + s - 1) / s;
+      g.Wa = (W - px + s - 1) / s;
+      g.ntaps = 0;
+      for (int kh = 0; kh < k; ++kh) {
+        if ((py + pt - kh) % s != 0) continue;
+        for (int kw = 0; kw < k; ++kw) {
+          if ((px + pl - kw) % s != 0) continue;
+          g.tap[g.ntaps++] = pack_tap((py + pt - kh) / s, (px + pl - kw) / s, kh * k + kw);
+        }
+      }
+    }
+  return 0;
+}
+
+// device helpers -------------------------------------------------------------------------------
+struct RowAnchor {
+  int b, ay, ax;  // image index, anchor*ss (source-space origin); ay = INT_MIN/2 marks an invalid row
+};
+
+__device__ inline void decode_row(const GatherParams& p, const GatherPhase& g, int m, int Mph, RowAnchor& r, int& dst) {
+  if (m < Mph) {
+    const int hw = g.Ha * g.Wa;
+    const int b = m / hw;
+    const int rem = m - b * hw;
+    const int a = rem / g.Wa;
+    const int bx = rem - a * g.Wa;
+    r.b = b; r.ay = a * p.ss; r.ax = bx * p.ss;
+    dst = (b * p.Hd + a * p.ds + g.py) * p.Wd + bx * p.ds + g.px;
+  } else {
+    r.b = 0; r.ay = -(1 << 28); r.ax = 0;
+    dst = -1;
+  }
+}
+
+__device__ inline float apply_epilogue(const GatherParams& p, float v, size_t idx, int n) {
+  if (p.bias) v += p.bias[n];
+  switch (p.epi_mode) {
+    case BG_EPI_BIAS_LRELU:
+      v = v > 0.f ? v : p.alpha * v;
+      if (p.keep) v = p.keep[idx] ? v * p.scale : 0.f;
+      break;
+    case BG_EPI_MUL_GRAD: {
+      float f = p.ref[idx] > 0.f ? 1.f : p.alpha;
+      if (p.keep) f = p.keep[idx] ? f * p.scale : 0.f;
+      v *= f;
+      break;
+    }
+    case BG_EPI_TANH:
+      v = tanhf(v);
+      break;
+    default:
+      break;
+  }
+  return v;
+}
+
+}  // namespace bg

@@ -1,0 +1,404 @@
+// Conv2D forward and data-gradient (== Conv2DTranspose forward) as implicit GEMM on fp32 MFMA.
+// Replaces layers.Conv2D / layers.Conv2DTranspose of reference demo_celeba.py:62-119 and the tape
+// gradients w.r.t. activations of wgan.py:140,166,244.
+//
+//   conv_igemm_kernel   MFMA path (v_mfma_f32_32x32x2_f32, exact fp32): C[M,N] = A_gather[M,K] * Wt[N,K]^T,
+//                       K = taps x channels, BK channels per step, A/B tiles staged through LDS with a
+//                       register-prefetched double buffer; epilogue fuses bias / LeakyReLU / dropout mask /
+//                       LeakyReLU-gradient mask / tanh.  MFMA-bound: 2*M*N*K flop.
+//   conv_thin_n_kernel  N <= 4 output channels (generator's last conv, MNIST ConvT->1): one thread per
+//                       output pixel, weights through the scalar cache.  VALU/HBM-bound.
+//   conv_thin_k_kernel  <= 4 input channels (critic's first conv, data-grad of the RGB conv): one thread
+//                       per output pixel x 32 output channels.  HBM-bound on the output write.
+//   conv_direct_kernel  catch-all for shapes the MFMA tiling cannot take (channel count not a multiple
+//                       of 16); used by small test geometries only.
+#include "conv_common.h"
+#include <algorithm>
+
+namespace {
+
+using bg::GatherParams;
+using bg::GatherPhase;
+using bg::RowAnchor;
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+// ------------------------------------------------------------------------------------------------
+// MFMA implicit GEMM
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const GatherParams p) {
+  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+  static_assert(BK == 16 || BK == 32, "BK");
+  constexpr int LD = BK + 4;                  // row stride (floats): 16-B aligned, conflict-free b128 reads
+  constexpr int TPR = BK / 4;                 // loader threads per row (one float4 each)
+  constexpr int RPP = 256 / TPR;              // rows per loader pass
+  constexpr int AP = (BM + RPP - 1) / RPP;    // loader passes for A
+  constexpr int BP = (BN + RPP - 1) / RPP;    // loader passes for B
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  static_assert(MI >= 1 && NI >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  constexpr int STAGE = (BM + BN) * LD;
+
+  __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+  __shared__ int rowdst[BM];
+
+  const GatherPhase& g = p.ph[blockIdx.z];
+  const int Mph = p.B * g.Ha * g.Wa;
+  const int m0 = blockIdx.x * BM;
+  if (m0 >= Mph) return;
+  const int n0 = blockIdx.y * BN;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+
+  // ---- loader bookkeeping
+  const int lrow = tid / TPR, lq = tid % TPR;
+  RowAnchor ra[AP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    int dst;
+    const int r = lrow + i * RPP;
+    bg::decode_row(p, g, (r < BM) ? m0 + r : Mph, Mph, ra[i], dst);
+  }
+  if (tid < BM) {
+    RowAnchor tmp;
+    int dst;
+    bg::decode_row(p, g, m0 + tid, Mph, tmp, dst);
+    rowdst[tid] = dst;
+  }
+
+  const int kchunks = p.Ck / BK;
+  const int nsteps = g.ntaps * kchunks;
+  float4 regA[AP], regB[BP];
+
+  auto gload = [&](int step) {
+    const int t = step / kchunks;
+    const int c0 = (step - t * kchunks) * BK + lq * 4;
+    const int tp = g.tap[t];
+    const int dy = bg::tap_dy(tp), dx = bg::tap_dx(tp), wi = bg::tap_wi(tp);
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int sy = ra[i].ay + dy, sx = ra[i].ax + dx;
+      const bool ok = (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (ok) v = *reinterpret_cast<const float4*>(p.A + ((size_t)(ra[i].b * p.Hs + sy) * p.Ws + sx) * p.Ck + c0);
+      regA[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int r = lrow + i * RPP;
+      const int n = n0 + r;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (r < BN && n < p.N) v = *reinterpret_cast<const float4*>(p.Wt + ((size_t)wi * p.N + n) * p.Ck + c0);
+      regB[i] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* sa = smem + buf * STAGE;
+    float* sb = sa + BM * LD;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int r = lrow + i * RPP;
+      if (r < BM) *reinterpret_cast<float4*>(sa + r * LD + lq * 4) = regA[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const int r = lrow + i * RPP;
+      if (r < BN) *reinterpret_cast<float4*>(sb + r * LD + lq * 4) = regB[i];
+    }
+  };
+
+  floatx16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  __syncthreads();
+
+  const int frow = lane & 31, fk = (lane >> 5) * 4;
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    if (step + 1 < nsteps) gload(step + 1);
+    const float* sa = smem + cur * STAGE + (wm * WTM + frow) * LD + fk;
+    const float* sb = smem + cur * STAGE + BM * LD + (wn * WTN + frow) * LD + fk;
+#pragma unroll
+    for (int ko = 0; ko < BK / 8; ++ko) {
+      float4 af[MI], bf[NI];
+#pragma unroll
+      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(sa + i * 32 * LD + ko * 8);
+#pragma unroll
+      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(sb + j * 32 * LD + ko * 8);
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+        }
+    }
+    if (step + 1 < nsteps) lstore(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: acc reg r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+  const int col = lane & 31, rhalf = (lane >> 5) * 4;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int n = n0 + wn * WTN + j * 32 + col;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+        const int dst = rowdst[row];
+        if (dst >= 0 && n < p.N) {
+          const size_t idx = (size_t)dst * p.N + n;
+          p.C[idx] = bg::apply_epilogue(p, acc[i][j][r], idx, n);
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// thin-N: one thread per output pixel, all N <= 4 channels; Ck % 4 == 0
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_thin_n_kernel(const GatherParams p) {
+  const GatherPhase& g = p.ph[blockIdx.z];
+  const int Mph = p.B * g.Ha * g.Wa;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= Mph) return;
+  RowAnchor ra;
+  int dst;
+  bg::decode_row(p, g, m, Mph, ra, dst);
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int N = p.N, Ck = p.Ck;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int tp = g.tap[t];
+    const int sy = ra.ay + bg::tap_dy(tp), sx = ra.ax + bg::tap_dx(tp);
+    if ((unsigned)sy >= (unsigned)p.Hs || (unsigned)sx >= (unsigned)p.Ws) continue;
+    const float* a = p.A + ((size_t)(ra.b * p.Hs + sy) * p.Ws + sx) * Ck;
+    const float* w = p.Wt + (size_t)bg::tap_wi(tp) * N * Ck;   // wave-uniform -> scalar loads
+    for (int c = 0; c < Ck; c += 4) {
+      const float4 av = *reinterpret_cast<const float4*>(a + c);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (n < N) {
+          const float4 wv = *reinterpret_cast<const float4*>(w + n * Ck + c);
+          acc[n] = fmaf(av.x, wv.x, acc[n]);
+          acc[n] = fmaf(av.y, wv.y, acc[n]);
+          acc[n] = fmaf(av.z, wv.z, acc[n]);
+          acc[n] = fmaf(av.w, wv.w, acc[n]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+    if (n < N) {
+      const size_t idx = (size_t)dst * N + n;
+      p.C[idx] = bg::apply_epilogue(p, acc[n], idx, n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// thin-K: Ck <= 4 input channels; one thread per output pixel x 32 consecutive output channels
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_thin_k_kernel(const GatherParams p) {
+  const GatherPhase& g = p.ph[blockIdx.z];
+  const int Mph = p.B * g.Ha * g.Wa;
+  const int m = blockIdx.x * 256 + threadIdx.x;
+  if (m >= Mph) return;
+  const int n0 = blockIdx.y * 32;
+  RowAnchor ra;
+  int dst;
+  bg::decode_row(p, g, m, Mph, ra, dst);
+  float acc[32];
+#pragma unroll
+  for (int n = 0; n < 32; ++n) acc[n] = 0.f;
+  const int N = p.N, Ck = p.Ck;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int tp = g.tap[t];
+    const int sy = ra.ay + bg::tap_dy(tp), sx = ra.ax + bg::tap_dx(tp);
+    if ((unsigned)sy >= (unsigned)p.Hs || (unsigned)sx >= (unsigned)p.Ws) continue;
+    const float* a = p.A + ((size_t)(ra.b * p.Hs + sy) * p.Ws + sx) * Ck;
+    const float* w = p.Wt + ((size_t)bg::tap_wi(tp) * N + n0) * Ck;   // wave-uniform
+    float av[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) av[c] = c < Ck ? a[c] : 0.f;
+#pragma unroll
+    for (int n = 0; n < 32; ++n) {
+      if (n0 + n < N) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < Ck) acc[n] = fmaf(av[c], w[n * Ck + c], acc[n]);
+      }
+    }
+  }
+#pragma unroll
+  for (int n = 0; n < 32; ++n)
+    if (n0 + n < N) {
+      const size_t idx = (size_t)dst * N + n0 + n;
+      p.C[idx] = bg::apply_epilogue(p, acc[n], idx, n0 + n);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// catch-all: one thread per output element
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void conv_direct_kernel(const GatherParams p) {
+  const GatherPhase& g = p.ph[blockIdx.z];
+  const int Mph = p.B * g.Ha * g.Wa;
+  const size_t e = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (e >= (size_t)Mph * p.N) return;
+  const int m = (int)(e / p.N), n = (int)(e - (size_t)m * p.N);
+  RowAnchor ra;
+  int dst;
+  bg::decode_row(p, g, m, Mph, ra, dst);
+  float acc = 0.f;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int tp = g.tap[t];
+    const int sy = ra.ay + bg::tap_dy(tp), sx = ra.ax + bg::tap_dx(tp);
+    if ((unsigned)sy >= (unsigned)p.Hs || (unsigned)sx >= (unsigned)p.Ws) continue;
+    const float* a = p.A + ((size_t)(ra.b * p.Hs + sy) * p.Ws + sx) * p.Ck;
+    const float* w = p.Wt + ((size_t)bg::tap_wi(tp) * p.N + n) * p.Ck;
+    for (int c = 0; c < p.Ck; ++c) acc = fmaf(a[c], w[c], acc);
+  }
+  const size_t idx = (size_t)dst * p.N + n;
+  p.C[idx] = bg::apply_epilogue(p, acc, idx, n);
+}
+
+__global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                              int R, int C) {
+  __shared__ float tile[32][33];
+  const float* s = src + (size_t)blockIdx.z * R * C;
+  float* d = dst + (size_t)blockIdx.z * R * C;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  for (int i = ty; i < 32; i += 8)
+    if (r0 + i < R && c0 + tx < C) tile[i][tx] = s[(size_t)(r0 + i) * C + c0 + tx];
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8)
+    if (c0 + i < C && r0 + tx < R) d[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// host dispatch
+// ------------------------------------------------------------------------------------------------
+int max_phase_m(const GatherParams& p) {
+  int mx = 0;
+  for (int i = 0; i < p.nphase; ++i) mx = std::max(mx, p.B * p.ph[i].Ha * p.ph[i].Wa);
+  return mx;
+}
+
+double gather_flops(const GatherParams& p) {
+  double f = 0;
+  for (int i = 0; i < p.nphase; ++i) f += 2.0 * p.B * p.ph[i].Ha * p.ph[i].Wa * (double)p.N * p.Ck * p.ph[i].ntaps;
+  return f;
+}
+
+template <int BM, int BN, int BK, int WMv, int WNv>
+int launch_igemm(const GatherParams& p, void* stream, const char* name) {
+  const int Mmax = max_phase_m(p);
+  dim3 grid(bg::cdiv(Mmax, BM), bg::cdiv(p.N, BN), p.nphase);
+  bg::Launch L(stream, name, gather_flops(p), 0);
+  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv>), grid, dim3(256), 0, L.s, p);
+  return L.done(name);
+}
+
+template <int BK>
+int dispatch_igemm(const GatherParams& p, void* stream, const char* tag) {
+  const int Mmax = max_phase_m(p);
+  auto wgs = [&](int bm, int bn) { return (long)bg::cdiv(Mmax, bm) * bg::cdiv(p.N, bn) * p.nphase; };
+  if (p.N > 64 && wgs(128, 128) >= 256) return launch_igemm<128, 128, BK, 2, 2>(p, stream, tag);
+  if (p.N > 32 && wgs(128, 64) >= 256) return launch_igemm<128, 64, BK, 2, 2>(p, stream, tag);
+  if (p.N <= 32) return launch_igemm<128, 32, BK, 4, 1>(p, stream, tag);
+  return launch_igemm<64, 64, BK, 2, 2>(p, stream, tag);
+}
+
+int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char* tag) {
+  p.epi_mode = BG_EPI_NONE; p.bias = nullptr; p.ref = nullptr; p.keep = nullptr; p.alpha = 0.3f; p.scale = 1.f;
+  if (epi) {
+    p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep;
+    p.alpha = epi->alpha; p.scale = epi->scale;
+    BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_TANH, BG_ERR_UNSUPPORTED, "%s: epilogue mode %d", tag, epi->mode);
+    BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || epi->ref, BG_ERR_NULL, "%s: BG_EPI_MUL_GRAD needs ref", tag);
+  }
+  const int Mmax = max_phase_m(p);
+  BG_REQUIRE((size_t)p.B * p.Hd * p.Wd * (size_t)p.N < (1ull << 31) && (size_t)p.B * p.Hs * p.Ws * (size_t)p.Ck < (1ull << 31),
+             BG_ERR_UNSUPPORTED, "%s: tensor exceeds 2^31 elements", tag);
+  char name[96];
+  if (p.Ck % 16 == 0 && p.N > 4) {
+    snprintf(name, sizeof name, "conv_igemm_%s", tag);
+    return (p.Ck % 32 == 0) ? dispatch_igemm<32>(p, stream, name) : dispatch_igemm<16>(p, stream, name);
+  }
+  if (p.N <= 4 && p.Ck % 4 == 0) {
+    snprintf(name, sizeof name, "conv_thin_n_%s", tag);
+    bg::Launch L(stream, name, gather_flops(p), 0);
+    hipLaunchKernelGGL(conv_thin_n_kernel, dim3(bg::cdiv(Mmax, 256), 1, p.nphase), dim3(256), 0, L.s, p);
+    return L.done(name);
+  }
+  if (p.Ck <= 4) {
+    snprintf(name, sizeof name, "conv_thin_k_%s", tag);
+    bg::Launch L(stream, name, gather_flops(p), 0);
+    hipLaunchKernelGGL(conv_thin_k_kernel, dim3(bg::cdiv(Mmax, 256), bg::cdiv(p.N, 32), p.nphase), dim3(256), 0, L.s, p);
+    return L.done(name);
+  }
+  snprintf(name, sizeof name, "conv_direct_%s", tag);
+  bg::Launch L(stream, name, gather_flops(p), 0);
+  hipLaunchKernelGGL(conv_direct_kernel, dim3(bg::cdiv((size_t)Mmax * p.N, 256), 1, p.nphase), dim3(256), 0, L.s, p);
+  return L.done(name);
+}
+
+int check_conv_args(const char* fn, const void* a, const void* w, const void* c, int B, int H, int W, int Cin, int Cout,
+                    int k, int s) {
+  BG_REQUIRE(a && w && c, BG_ERR_NULL, "%s: null pointer", fn);
+  BG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cout > 0, BG_ERR_BAD_SHAPE, "%s: B=%d H=%d W=%d Cin=%d Cout=%d", fn, B, H, W, Cin, Cout);
+  BG_REQUIRE(k >= 1 && (k & 1) && k * k <= bg::kMaxTaps, BG_ERR_UNSUPPORTED, "%s: kernel size %d (odd, <= 5 supported)", fn, k);
+  BG_REQUIRE(s == 1 || s == 2, BG_ERR_UNSUPPORTED, "%s: stride %d (1 or 2 supported)", fn, s);
+  BG_REQUIRE(bg::aligned16(a) && bg::aligned16(w) && bg::aligned16(c), BG_ERR_BAD_ALIGNMENT, "%s: pointers must be 16-byte aligned", fn);
+  return BG_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int W, int Cin, int Cout, int ksize,
+                  int stride, const bg_epilogue* epi, void* stream) {
+  int rc = check_conv_args("bg_conv2d_fwd", x, wT_d, y, B, H, W, Cin, Cout, ksize, stride);
+  if (rc) return rc;
+  GatherParams p;
+  memset(&p, 0, sizeof p);
+  bg::make_fwd_params(p, B, H, W, Cin, Cout, ksize, stride);
+  p.A = x; p.Wt = wT_d; p.C = y;
+  return run_gather(p, epi, stream, "fwd");
+}
+
+int bg_conv2d_bwd_data(const float* dy, const float* w_d, float* dx, int B, int H, int W, int Cin, int Cout, int ksize,
+                       int stride, const bg_epilogue* epi, void* stream) {
+  int rc = check_conv_args("bg_conv2d_bwd_data", dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride);
+  if (rc) return rc;
+  GatherParams p;
+  memset(&p, 0, sizeof p);
+  bg::make_bwd_data_params(p, B, H, W, Cin, Cout, ksize, stride);
+  p.A = dy; p.Wt = w_d; p.C = dx;
+  return run_gather(p, epi, stream, "dgrad");
+}
+
+int bg_transpose_last2(const float* src, float* dst, int T, int R, int C, void* stream) {
+  BG_REQUIRE(src && dst, BG_ERR_NULL, "bg_transpose_last2: null pointer");
+  BG_REQUIRE(T > 0 && R > 0 && C > 0 && T <= 65535, BG_ERR_BAD_SHAPE, "bg_transpose_last2: T=%d R=%d C=%d", T, R, C);
+  bg::Launch L(stream, "transpose_last2", 0, 8.0 * T * R * C);
+  hipLaunchKernelGGL(transpose_last2_kernel, dim3(bg::cdiv(C, 32), bg::cdiv(R, 32), T), dim3(256), 0, L.s, src, dst, R, C);
+  return L.done("transpose_last2_kernel");
+}
+
+}  // extern "C"

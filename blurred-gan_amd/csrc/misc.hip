@@ -1,0 +1,561 @@
+// HBM-bound support ops of the training step: Dense, column reductions, BatchNorm(+LeakyReLU),
+// pointwise GP helpers, losses, Adam, RNG.  Each replaces the TF op named beside it
+// (SURVEY.md 8a rows T4-T12); all are bandwidth-bound, written as coalesced grid-stride kernels.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+constexpr int kT = 256;
+
+inline unsigned grid_for(size_t n, int per_thread = 1) {
+  return (unsigned)std::max<size_t>(1, std::min<size_t>(bg::cdiv(n, (size_t)kT * per_thread), 256 * 8));
+}
+
+// ---------------------------------------------------------------- Dense (layers.Dense, demo_celeba.py:55,124)
+__global__ __launch_bounds__(kT) void gemm_naive_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                        float* __restrict__ C, int M, int N, int K, int transA, int transB,
+                                                        const float* __restrict__ bias, float beta, float scale) {
+  const size_t total = (size_t)M * N;
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < total; e += (size_t)gridDim.x * kT) {
+    const int m = (int)(e / N), n = (int)(e - (size_t)m * N);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+      const float a = transA ? A[(size_t)k * M + m] : A[(size_t)m * K + k];
+      const float b = transB ? Bm[(size_t)n * K + k] : Bm[(size_t)k * N + n];
+      acc = fmaf(a, b, acc);
+    }
+    float v = scale * acc;
+    if (bias) v += bias[n];
+    if (beta != 0.f) v += beta * C[e];
+    C[e] = v;
+  }
+}
+
+// N == 1, no transposes: one wave per row (critic's Dense(2048 -> 1))
+__global__ __launch_bounds__(kT) void rowdot_kernel(const float* __restrict__ A, const float* __restrict__ w, float* __restrict__ C,
+                                                    int M, int K, const float* __restrict__ bias, float beta, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const float* a = A + (size_t)row * K;
+  float acc = 0.f;
+  for (int k = lane; k < K; k += 64) acc = fmaf(a[k], w[k], acc);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if (lane == 0) {
+    float v = scale * acc;
+    if (bias) v += bias[0];
+    if (beta != 0.f) v += beta * C[row];
+    C[row] = v;
+  }
+}
+
+// ---------------------------------------------------------------- column reductions
+// Block = 4 row-lanes x 64 columns; grid (row blocks, column groups); partial[blockIdx.x][q][n].
+constexpr int kColBlocks = 256;
+
+template <int NQ, class F>
+__device__ inline void col_reduce(F f, int M, int N, float* partial) {
+  __shared__ float red[NQ][4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.y * 64 + tx;
+  float acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = 0.f;
+  if (n < N) {
+    const int rows_per = (M + gridDim.x - 1) / gridDim.x;
+    const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+    for (int m = r0 + ty; m < r1; m += 4) f(m, n, acc);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) red[q][ty][tx] = acc[q];
+  __syncthreads();
+  if (ty == 0 && n < N) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q)
+      partial[((size_t)blockIdx.x * NQ + q) * N + n] = red[q][0][tx] + red[q][1][tx] + red[q][2][tx] + red[q][3][tx];
+  }
+}
+
+__global__ __launch_bounds__(kT) void colsum_partial_kernel(const float* __restrict__ x, int M, int N, int square, float* partial) {
+  col_reduce<1>([&](int m, int n, float* a) {
+    const float v = x[(size_t)m * N + n];
+    a[0] += square ? v * v : v;
+  }, M, N, partial);
+}
+
+__global__ __launch_bounds__(kT) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int N, float* out, float beta,
+                                                          float scale) {
+  const int n = blockIdx.x * kT + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * N + n];
+  out[n] = (beta != 0.f ? beta * out[n] : 0.f) + scale * s;
+}
+
+int col_blocks(int M) { return std::max(1, std::min(kColBlocks, M / 16)); }
+
+// ---------------------------------------------------------------- BatchNormalization + LeakyReLU
+__global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const float* __restrict__ x, int M, int C, float* partial) {
+  col_reduce<2>([&](int m, int n, float* a) {
+    const float v = x[(size_t)m * C + n];
+    a[0] += v;
+    a[1] = fmaf(v, v, a[1]);
+  }, M, C, partial);
+}
+
+__global__ __launch_bounds__(kT) void bn_stats_final_kernel(const float* __restrict__ partial, int nblk, int M, int C, float* save_mean,
+                                                            float* save_inv, float* moving_mean, float* moving_var, float eps,
+                                                            float momentum, int unbiased) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, s2 = 0.f;
+  for (int b = 0; b < nblk; ++b) {
+    s += partial[((size_t)b * 2 + 0) * C + c];
+    s2 += partial[((size_t)b * 2 + 1) * C + c];
+  }
+  const float mean = s / (float)M;
+  const float var = fmaxf(s2 / (float)M - mean * mean, 0.f);
+  save_mean[c] = mean;
+  save_inv[c] = 1.0f / sqrtf(var + eps);
+  if (moving_mean) {
+    const float vu = unbiased ? var * ((float)M / (float)max(M - 1, 1)) : var;
+    moving_mean[c] = moving_mean[c] * momentum + mean * (1.f - momentum);
+    moving_var[c] = moving_var[c] * momentum + vu * (1.f - momentum);
+  }
+}
+
+// y = lrelu(gamma*(x-mean)*inv + beta); mean/inv either saved batch stats or derived from moving stats
+__global__ __launch_bounds__(kT) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int C,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ inv_or_var,
+                                                      int is_var, float eps, float alpha) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < total; e += (size_t)gridDim.x * kT) {
+    const int c = (int)(e % C);
+    const float inv = is_var ? 1.0f / sqrtf(inv_or_var[c] + eps) : inv_or_var[c];
+    float v = gamma[c] * ((x[e] - mean[c]) * inv) + beta[c];
+    y[e] = v > 0.f ? v : alpha * v;
+  }
+}
+
+__global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                            const float* __restrict__ x, int M, int C,
+                                                            const float* __restrict__ mean, const float* __restrict__ inv, float alpha,
+                                                            float* partial) {
+  col_reduce<2>([&](int m, int n, float* a) {
+    const size_t e = (size_t)m * C + n;
+    const float dz = dy[e] * (y[e] > 0.f ? 1.f : alpha);
+    a[0] += dz;
+    a[1] = fmaf(dz, (x[e] - mean[n]) * inv[n], a[1]);
+  }, M, C, partial);
+}
+
+__global__ __launch_bounds__(kT) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C, float* dgamma, float* dbeta) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f, s2 = 0.f;
+  for (int b = 0; b < nblk; ++b) {
+    s += partial[((size_t)b * 2 + 0) * C + c];
+    s2 += partial[((size_t)b * 2 + 1) * C + c];
+  }
+  dbeta[c] = s;
+  dgamma[c] = s2;
+}
+
+__global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                          const float* __restrict__ x, float* __restrict__ dx, size_t total, int M, int C,
+                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ inv, const float* __restrict__ dgamma,
+                                                          const float* __restrict__ dbeta, float alpha) {
+  const float invM = 1.0f / (float)M;
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < total; e += (size_t)gridDim.x * kT) {
+    const int c = (int)(e % C);
+    const float dz = dy[e] * (y[e] > 0.f ? 1.f : alpha);
+    const float xh = (x[e] - mean[c]) * inv[c];
+    dx[e] = gamma[c] * inv[c] * invM * ((float)M * dz - dbeta[c] - xh * dgamma[c]);
+  }
+}
+
+// ---------------------------------------------------------------- pointwise
+__global__ __launch_bounds__(kT) void lerp_kernel(const float* __restrict__ r, const float* __restrict__ f, const float* __restrict__ alpha,
+                                                  float* __restrict__ out, size_t total, int n_per) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < total; e += (size_t)gridDim.x * kT) {
+    const float a = alpha[e / n_per];
+    out[e] = r[e] + a * (f[e] - r[e]);
+  }
+}
+
+__global__ __launch_bounds__(kT) void row_norm_kernel(const float* __restrict__ g, float* __restrict__ norm, int n_per) {
+  __shared__ float red[kT / 64];
+  const float* row = g + (size_t)blockIdx.x * n_per;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n_per; i += kT) acc = fmaf(row[i], row[i], acc);
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) norm[blockIdx.x] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(kT) void gp_seed_kernel(const float* __restrict__ g, const float* __restrict__ norm, float coef,
+                                                     float* __restrict__ out, size_t total, int n_per) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < total; e += (size_t)gridDim.x * kT) {
+    const float n = norm[e / n_per];
+    out[e] = coef * ((n - 1.f) / n) * g[e];
+  }
+}
+
+__global__ __launch_bounds__(kT) void mul_grad_kernel(const float* __restrict__ d, const float* __restrict__ ref,
+                                                      const uint8_t* __restrict__ keep, float alpha, float scale,
+                                                      float* __restrict__ out, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < n; e += (size_t)gridDim.x * kT) {
+    float f = ref[e] > 0.f ? 1.f : alpha;
+    if (keep) f = keep[e] ? f * scale : 0.f;
+    out[e] = d[e] * f;
+  }
+}
+
+__global__ __launch_bounds__(kT) void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, float* __restrict__ out,
+                                                      size_t n) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < n; e += (size_t)gridDim.x * kT) out[e] = dy[e] * (1.f - y[e] * y[e]);
+}
+
+__global__ __launch_bounds__(kT) void outer_kernel(const float* __restrict__ s, const float* __restrict__ w, float* __restrict__ out,
+                                                   size_t total, int K) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < total; e += (size_t)gridDim.x * kT) out[e] = s[e / K] * w[e % K];
+}
+
+__global__ __launch_bounds__(kT) void fill_kernel(float* x, float v, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < n; e += (size_t)gridDim.x * kT) x[e] = v;
+}
+
+__global__ __launch_bounds__(kT) void scale_kernel(float* x, float v, size_t n) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < n; e += (size_t)gridDim.x * kT) x[e] *= v;
+}
+
+// ---------------------------------------------------------------- losses (single workgroup; B is small)
+__device__ inline float block_sum(float v, float* red) {
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__device__ inline float sgnf(float v) { return v > 0.f ? 1.f : (v < 0.f ? -1.f : 0.f); }
+
+__global__ __launch_bounds__(kT) void d_loss_kernel(const float* __restrict__ fs, const float* __restrict__ rs,
+                                                    const float* __restrict__ norm, int B, float inv_gbs, float gp_coef, float e_drift,
+                                                    float vec_scale, float* dfs, float* drs, float* metrics) {
+  __shared__ float red[4];
+  float sf = 0.f, sr = 0.f, sn = 0.f, sg = 0.f;
+  for (int b = threadIdx.x; b < B; b += kT) {
+    const float f = fs[b], r = rs[b];
+    sf += f;
+    sr += r;
+    sn += e_drift * (fabsf(f) + fabsf(r));
+    if (norm) {
+      const float d = norm[b] - 1.f;
+      sg = fmaf(d, d, sg);
+    }
+    dfs[b] = vec_scale * inv_gbs + e_drift * sgnf(f);
+    drs[b] = -vec_scale * inv_gbs + e_drift * sgnf(r);
+  }
+  sf = block_sum(sf, red);
+  sr = block_sum(sr, red);
+  sn = block_sum(sn, red);
+  sg = block_sum(sg, red);
+  if (threadIdx.x == 0) {
+    const float gp = sg / (float)B;
+    const float lw = (sf - sr) * inv_gbs;
+    metrics[0] = sf / (float)B;
+    metrics[1] = sr / (float)B;
+    metrics[2] = lw + gp_coef * gp + sn / (float)B;   // mean of the [B] loss vector (wgan.py:145)
+    metrics[3] = gp_coef * gp;
+    metrics[4] = sn / (float)B;
+    metrics[5] = gp;
+  }
+}
+
+__global__ __launch_bounds__(kT) void g_loss_kernel(const float* __restrict__ s, int B, float inv_gbs, float* ds, float* metrics) {
+  __shared__ float red[4];
+  float ss = 0.f;
+  for (int b = threadIdx.x; b < B; b += kT) {
+    ss += s[b];
+    ds[b] = -inv_gbs;
+  }
+  ss = block_sum(ss, red);
+  if (threadIdx.x == 0) {
+    metrics[0] = ss / (float)B;
+    metrics[1] = -ss * inv_gbs;
+  }
+}
+
+// ---------------------------------------------------------------- Adam
+__global__ __launch_bounds__(kT) void adam_kernel(float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v,
+                                                  const float* __restrict__ g, size_t n, float lr_t, float b1, float b2, float eps) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < n; e += (size_t)gridDim.x * kT) {
+    const float gi = g[e];
+    const float mi = b1 * m[e] + (1.f - b1) * gi;
+    const float vi = b2 * v[e] + (1.f - b2) * gi * gi;
+    m[e] = mi;
+    v[e] = vi;
+    theta[e] = theta[e] - lr_t * mi / (sqrtf(vi) + eps);
+  }
+}
+
+// ---------------------------------------------------------------- RNG: Philox4x32-10, counter = element index / 4
+__device__ inline void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+__device__ inline float u01(uint32_t x) { return (float)(x >> 8) * (1.0f / 16777216.0f); }
+
+__global__ __launch_bounds__(kT) void uniform_kernel(float* out, size_t n, uint64_t seed, uint64_t offset) {
+  const size_t nq = (n + 3) / 4;
+  for (size_t q = (size_t)blockIdx.x * kT + threadIdx.x; q < nq; q += (size_t)gridDim.x * kT) {
+    const uint64_t ctr = offset + q;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 0u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (q * 4 + i < n) out[q * 4 + i] = u01(r[i]);
+  }
+}
+
+__global__ __launch_bounds__(kT) void keep_mask_kernel(uint8_t* out, size_t n, float keep_prob, uint64_t seed, uint64_t offset) {
+  const size_t nq = (n + 3) / 4;
+  for (size_t q = (size_t)blockIdx.x * kT + threadIdx.x; q < nq; q += (size_t)gridDim.x * kT) {
+    const uint64_t ctr = offset + q;
+    uint32_t r[4];
+    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+      if (q * 4 + i < n) out[q * 4 + i] = u01(r[i]) < keep_prob ? 1 : 0;
+  }
+}
+
+}  // namespace
+
+#define BG_POINTWISE_PROLOGUE(fn, cond, n_)                                     \
+  BG_REQUIRE(cond, BG_ERR_NULL, fn ": null pointer");                           \
+  BG_REQUIRE((n_) > 0, BG_ERR_BAD_SHAPE, fn ": empty tensor")
+
+extern "C" {
+
+int bg_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, int transA, int transB, const float* bias,
+                float beta, float scale, void* stream) {
+  BG_REQUIRE(A && Bm && C, BG_ERR_NULL, "bg_gemm_f32: null pointer");
+  BG_REQUIRE(M > 0 && N > 0 && K > 0, BG_ERR_BAD_SHAPE, "bg_gemm_f32: M=%d N=%d K=%d", M, N, K);
+  const double flops = 2.0 * M * (double)N * K;
+  if (N == 1 && !transA && K >= 64) {
+    bg::Launch L(stream, "dense_rowdot", flops, 4.0 * M * K);
+    hipLaunchKernelGGL(rowdot_kernel, dim3(bg::cdiv(M, kT / 64)), dim3(kT), 0, L.s, A, Bm, C, M, K, bias, beta, scale);
+    return L.done("rowdot_kernel");
+  }
+  bg::Launch L(stream, "dense_gemm", flops, 0);
+  hipLaunchKernelGGL(gemm_naive_kernel, dim3(grid_for((size_t)M * N)), dim3(kT), 0, L.s, A, Bm, C, M, N, K, transA, transB, bias, beta, scale);
+  return L.done("gemm_naive_kernel");
+}
+
+size_t bg_colsum_workspace_bytes(int M, int N) {
+  if (M <= 0 || N <= 0) return 0;
+  return (size_t)col_blocks(M) * 2 * N * sizeof(float);
+}
+
+int bg_colsum_f32(const float* x, float* out, int M, int N, int square, float beta, float scale, void* ws_d, size_t ws_bytes,
+                  void* stream) {
+  BG_REQUIRE(x && out, BG_ERR_NULL, "bg_colsum_f32: null pointer");
+  BG_REQUIRE(M > 0 && N > 0, BG_ERR_BAD_SHAPE, "bg_colsum_f32: M=%d N=%d", M, N);
+  BG_REQUIRE(ws_d && ws_bytes >= bg_colsum_workspace_bytes(M, N), BG_ERR_WORKSPACE, "bg_colsum_f32: workspace too small");
+  const int nblk = col_blocks(M);
+  float* partial = static_cast<float*>(ws_d);
+  {
+    bg::Launch L(stream, "colsum_partial", 0, 4.0 * M * N);
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, bg::cdiv(N, 64)), dim3(kT), 0, L.s, x, M, N, square, partial);
+    int rc = L.done("colsum_partial_kernel");
+    if (rc) return rc;
+  }
+  bg::Launch L(stream, "colsum_final", 0, 0);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(bg::cdiv(N, kT)), dim3(kT), 0, L.s, partial, nblk, N, out, beta, scale);
+  return L.done("colsum_final_kernel");
+}
+
+size_t bg_bn_workspace_bytes(int M, int C) { return bg_colsum_workspace_bytes(M, C); }
+
+int bg_bn_train_fwd(const float* x, float* y, int M, int C, const float* gamma, const float* beta, float* moving_mean,
+                    float* moving_var, float* save_mean, float* save_inv, float eps, float momentum, int unbiased,
+                    float lrelu_alpha, void* ws_d, size_t ws_bytes, void* stream) {
+  BG_REQUIRE(x && y && gamma && beta && save_mean && save_inv, BG_ERR_NULL, "bg_bn_train_fwd: null pointer");
+  BG_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), BG_ERR_NULL, "bg_bn_train_fwd: moving_mean/var must both be given or both NULL");
+  BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_train_fwd: M=%d C=%d", M, C);
+  BG_REQUIRE(ws_d && ws_bytes >= bg_bn_workspace_bytes(M, C), BG_ERR_WORKSPACE, "bg_bn_train_fwd: workspace too small");
+  const int nblk = col_blocks(M);
+  float* partial = static_cast<float*>(ws_d);
+  const size_t total = (size_t)M * C;
+  {
+    bg::Launch L(stream, "bn_stats_partial", 0, 4.0 * total);
+    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, x, M, C, partial);
+    int rc = L.done("bn_stats_partial_kernel");
+    if (rc) return rc;
+  }
+  {
+    bg::Launch L(stream, "bn_stats_final", 0, 0);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, partial, nblk, M, C, save_mean, save_inv,
+                       moving_mean, moving_var, eps, momentum, unbiased);
+    int rc = L.done("bn_stats_final_kernel");
+    if (rc) return rc;
+  }
+  bg::Launch L(stream, "bn_apply_lrelu", 0, 8.0 * total);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, save_mean, save_inv, 0, eps,
+                     lrelu_alpha);
+  return L.done("bn_apply_kernel");
+}
+
+int bg_bn_infer_fwd(const float* x, float* y, int M, int C, const float* gamma, const float* beta, const float* moving_mean,
+                    const float* moving_var, float eps, float lrelu_alpha, void* stream) {
+  BG_REQUIRE(x && y && gamma && beta && moving_mean && moving_var, BG_ERR_NULL, "bg_bn_infer_fwd: null pointer");
+  BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_infer_fwd: M=%d C=%d", M, C);
+  const size_t total = (size_t)M * C;
+  bg::Launch L(stream, "bn_apply_lrelu", 0, 8.0 * total);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, moving_mean, moving_var, 1,
+                     eps, lrelu_alpha);
+  return L.done("bn_apply_kernel");
+}
+
+int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, int M, int C, const float* gamma,
+                    const float* save_mean, const float* save_inv, float* dgamma, float* dbeta, float lrelu_alpha, void* ws_d,
+                    size_t ws_bytes, void* stream) {
+  BG_REQUIRE(dy && y && x && dx && gamma && save_mean && save_inv && dgamma && dbeta, BG_ERR_NULL, "bg_bn_train_bwd: null pointer");
+  BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_train_bwd: M=%d C=%d", M, C);
+  BG_REQUIRE(ws_d && ws_bytes >= bg_bn_workspace_bytes(M, C), BG_ERR_WORKSPACE, "bg_bn_train_bwd: workspace too small");
+  const int nblk = col_blocks(M);
+  float* partial = static_cast<float*>(ws_d);
+  const size_t total = (size_t)M * C;
+  {
+    bg::Launch L(stream, "bn_bwd_partial", 0, 12.0 * total);
+    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv,
+                       lrelu_alpha, partial);
+    int rc = L.done("bn_bwd_partial_kernel");
+    if (rc) return rc;
+  }
+  {
+    bg::Launch L(stream, "bn_bwd_final", 0, 0);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, partial, nblk, C, dgamma, dbeta);
+    int rc = L.done("bn_bwd_final_kernel");
+    if (rc) return rc;
+  }
+  bg::Launch L(stream, "bn_bwd_apply", 0, 16.0 * total);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M, C, gamma, save_mean, save_inv,
+                     dgamma, dbeta, lrelu_alpha);
+  return L.done("bn_bwd_apply_kernel");
+}
+
+int bg_lerp_f32(const float* r, const float* f, const float* alpha_b, float* xhat, int B, int n_per, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_lerp_f32", r && f && alpha_b && xhat, (long)B * n_per);
+  const size_t total = (size_t)B * n_per;
+  bg::Launch L(stream, "lerp", 0, 12.0 * total);
+  hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, r, f, alpha_b, xhat, total, n_per);
+  return L.done("lerp_kernel");
+}
+
+int bg_row_norm_f32(const float* g, float* norm_b, int B, int n_per, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_row_norm_f32", g && norm_b, (long)B * n_per);
+  bg::Launch L(stream, "row_norm", 0, 4.0 * B * n_per);
+  hipLaunchKernelGGL(row_norm_kernel, dim3(B), dim3(kT), 0, L.s, g, norm_b, n_per);
+  return L.done("row_norm_kernel");
+}
+
+int bg_gp_seed_f32(const float* g, const float* norm_b, float coef, float* out, int B, int n_per, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_gp_seed_f32", g && norm_b && out, (long)B * n_per);
+  const size_t total = (size_t)B * n_per;
+  bg::Launch L(stream, "gp_seed", 0, 8.0 * total);
+  hipLaunchKernelGGL(gp_seed_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, g, norm_b, coef, out, total, n_per);
+  return L.done("gp_seed_kernel");
+}
+
+int bg_mul_grad_f32(const float* d, const float* ref, const uint8_t* keep, float alpha, float scale, float* out, size_t n,
+                    void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_mul_grad_f32", d && ref && out, n);
+  bg::Launch L(stream, "mul_grad", 0, 12.0 * n);
+  hipLaunchKernelGGL(mul_grad_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, d, ref, keep, alpha, scale, out, n);
+  return L.done("mul_grad_kernel");
+}
+
+int bg_tanh_bwd_f32(const float* dy, const float* y, float* out, size_t n, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_tanh_bwd_f32", dy && y && out, n);
+  bg::Launch L(stream, "tanh_bwd", 0, 12.0 * n);
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, dy, y, out, n);
+  return L.done("tanh_bwd_kernel");
+}
+
+int bg_outer_f32(const float* s_b, const float* w_k, float* out, int B, int K, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_outer_f32", s_b && w_k && out, (long)B * K);
+  const size_t total = (size_t)B * K;
+  bg::Launch L(stream, "outer", 0, 4.0 * total);
+  hipLaunchKernelGGL(outer_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, s_b, w_k, out, total, K);
+  return L.done("outer_kernel");
+}
+
+int bg_fill_f32(float* x, float v, size_t n, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_fill_f32", x, n);
+  bg::Launch L(stream, "fill", 0, 4.0 * n);
+  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, x, v, n);
+  return L.done("fill_kernel");
+}
+
+int bg_scale_f32(float* x, float v, size_t n, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_scale_f32", x, n);
+  bg::Launch L(stream, "scale", 0, 8.0 * n);
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, x, v, n);
+  return L.done("scale_kernel");
+}
+
+int bg_wgangp_d_loss(const float* fs, const float* rs, const float* norm_b, int B, float inv_gbs, float gp_coef, float e_drift,
+                     float vec_scale, float* dfs, float* drs, float* metrics_d, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_wgangp_d_loss", fs && rs && dfs && drs && metrics_d, B);
+  bg::Launch L(stream, "d_loss", 0, 0);
+  hipLaunchKernelGGL(d_loss_kernel, dim3(1), dim3(kT), 0, L.s, fs, rs, norm_b, B, inv_gbs, gp_coef, e_drift, vec_scale, dfs, drs, metrics_d);
+  return L.done("d_loss_kernel");
+}
+
+int bg_wgan_g_loss(const float* s, int B, float inv_gbs, float* ds, float* metrics_d, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_wgan_g_loss", s && ds && metrics_d, B);
+  bg::Launch L(stream, "g_loss", 0, 0);
+  hipLaunchKernelGGL(g_loss_kernel, dim3(1), dim3(kT), 0, L.s, s, B, inv_gbs, ds, metrics_d);
+  return L.done("g_loss_kernel");
+}
+
+int bg_adam_f32(float* theta, float* m, float* v, const float* g, size_t n, float lr_t, float b1, float b2, float eps,
+                void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_adam_f32", theta && m && v && g, n);
+  bg::Launch L(stream, "adam", 0, 28.0 * n);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, theta, m, v, g, n, lr_t, b1, b2, eps);
+  return L.done("adam_kernel");
+}
+
+int bg_uniform_f32(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_uniform_f32", out, n);
+  bg::Launch L(stream, "rng_uniform", 0, 4.0 * n);
+  hipLaunchKernelGGL(uniform_kernel, dim3(grid_for(n, 4)), dim3(kT), 0, L.s, out, n, seed, offset);
+  return L.done("uniform_kernel");
+}
+
+int bg_keep_mask_u8(uint8_t* out, size_t n, float keep_prob, uint64_t seed, uint64_t offset, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_keep_mask_u8", out, n);
+  BG_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, BG_ERR_BAD_SHAPE, "bg_keep_mask_u8: keep_prob=%g", keep_prob);
+  bg::Launch L(stream, "rng_keep_mask", 0, 1.0 * n);
+  hipLaunchKernelGGL(keep_mask_kernel, dim3(grid_for(n, 4)), dim3(kT), 0, L.s, out, n, keep_prob, seed, offset);
+  return L.done("keep_mask_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,105 @@
+// Meta entry points, thread-local error message, per-launch HIP-event profiling (bench.py roofline).
+#include "common.h"
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace bg {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+}
+
+struct ProfRec {
+  std::string name;
+  double flops, bytes;
+  hipEvent_t e0, e1;
+};
+static bool g_prof = false;
+static std::vector<ProfRec> g_recs;
+static std::mutex g_mu;
+
+bool prof_on() { return g_prof; }
+
+void prof_begin(hipStream_t s, const char* name, double flops, double bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  ProfRec r;
+  r.name = name;
+  r.flops = flops;
+  r.bytes = bytes;
+  (void)hipEventCreate(&r.e0);
+  (void)hipEventCreate(&r.e1);
+  (void)hipEventRecord(r.e0, s);
+  g_recs.push_back(r);
+}
+
+void prof_end(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, s);
+}
+
+}  // namespace bg
+
+extern "C" {
+
+int bg_version(void) { return BG_ABI_VERSION; }
+
+const char* bg_last_error(void) { return bg::g_err; }
+
+const char* bg_status_string(int s) {
+  switch (s) {
+    case BG_OK: return "ok";
+    case BG_ERR_BAD_SHAPE: return "bad shape";
+    case BG_ERR_BAD_ALIGNMENT: return "bad alignment";
+    case BG_ERR_UNSUPPORTED: return "unsupported configuration";
+    case BG_ERR_HIP: return "HIP runtime error";
+    case BG_ERR_WORKSPACE: return "workspace missing or too small";
+    case BG_ERR_NULL: return "null pointer";
+    default: return "unknown status";
+  }
+}
+
+int bg_prof_enable(int on) {
+  bg::g_prof = on != 0;
+  return BG_OK;
+}
+
+int bg_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(bg::g_mu);
+  for (auto& r : bg::g_recs) {
+    (void)hipEventDestroy(r.e0);
+    (void)hipEventDestroy(r.e1);
+  }
+  bg::g_recs.clear();
+  return BG_OK;
+}
+
+int bg_prof_count(void) {
+  std::lock_guard<std::mutex> lk(bg::g_mu);
+  if (!bg::g_recs.empty()) (void)hipEventSynchronize(bg::g_recs.back().e1);
+  return (int)bg::g_recs.size();
+}
+
+int bg_prof_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes) {
+  std::lock_guard<std::mutex> lk(bg::g_mu);
+  if (i < 0 || i >= (int)bg::g_recs.size()) return bg::fail(BG_ERR_BAD_SHAPE, "bg_prof_get: index %d out of range", i);
+  auto& r = bg::g_recs[i];
+  if (name && name_cap > 0) {
+    strncpy(name, r.name.c_str(), name_cap - 1);
+    name[name_cap - 1] = 0;
+  }
+  float t = 0;
+  hipError_t e = hipEventElapsedTime(&t, r.e0, r.e1);
+  if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "bg_prof_get: %s", hipGetErrorString(e));
+  if (ms) *ms = t;
+  if (flops) *flops = r.flops;
+  if (bytes) *bytes = r.bytes;
+  return BG_OK;
+}
+
+}  // extern "C"

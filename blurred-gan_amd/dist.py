@@ -1,0 +1,67 @@
+"""Data-parallel plumbing: one process per GPU, ``torch.distributed`` (backend "nccl" == RCCL over xGMI on
+ROCm; "gloo" for the CPU tests).  The reference never ran multi-GPU (wgan.py:89 "TODO: Distributed
+training"); the build defines DP == the single-device step at the global batch: replicas
+shard the minibatch, parameters and Adam state are replicated, and the flat gradient buffer of each
+network is SUM all-reduced once per optimiser step (losses are already written for SUM semantics,
+wgan.py:130,157)."""
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as td
+
+
+def is_initialized():
+    return td.is_available() and td.is_initialized()
+
+
+def rank():
+    return td.get_rank() if is_initialized() else 0
+
+
+def world_size():
+    return td.get_world_size() if is_initialized() else 1
+
+
+def local_rank():
+    return int(os.environ.get("LOCAL_RANK", "0"))
+
+
+def init_from_env(backend=None):
+    """Joins the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
+    ws = int(os.environ.get("WORLD_SIZE", "1"))
+    if ws <= 1 or is_initialized():
+        return world_size()
+    use_cuda = torch.cuda.is_available()
+    if use_cuda:
+        torch.cuda.set_device(local_rank())
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    td.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"))
+    return world_size()
+
+
+def all_reduce_sum_(flat):
+    """In-place SUM all-reduce of a flat gradient buffer (no-op for a single replica)."""
+    if world_size() > 1:
+        td.all_reduce(flat, op=td.ReduceOp.SUM)
+    return flat
+
+
+def broadcast_(flat, src=0):
+    if world_size() > 1:
+        td.broadcast(flat, src=src)
+    return flat
+
+
+def barrier():
+    if world_size() > 1:
+        td.barrier()
+
+
+def shard(batch, r=None, n=None):
+    """The slice of a global batch this replica trains on (equal shards)."""
+    r = rank() if r is None else r
+    n = world_size() if n is None else n
+    per = batch.shape[0] // n
+    return batch[r * per:(r + 1) * per]

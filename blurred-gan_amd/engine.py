@@ -1,0 +1,347 @@
+"""Executor: compiles a flattened layer list into fused stages and runs forward / backward / the
+gradient-penalty linearised forward on the HIP kernels.  There is no tape: every backward formula is
+written out (SURVEY.md 8a, rows T1-T8 and the GP second-order derivation).
+
+A stage = one linear op (Dense | Conv2D | Conv2DTranspose) [+ bias] [+ BatchNormalization] [+ LeakyReLU |
+tanh] [+ Dropout]; Reshape / Flatten are views.  Stage fusion on the device:
+  conv (+bias) + LeakyReLU + Dropout      -> one launch (epilogue of the MFMA kernel)
+  dgrad + LeakyReLU'/Dropout' of the stage below -> one launch (BG_EPI_MUL_GRAD epilogue)
+  BatchNormalization + LeakyReLU          -> stats pass + one apply pass
+"""
+from __future__ import annotations
+
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH
+
+
+class Stage:
+    def __init__(self, lin, in_shape):
+        self.lin = lin
+        self.kind = lin.kind
+        self.in_shape = tuple(in_shape)
+        self.out_shape = tuple(lin.out_shape(in_shape))
+        self.bn = None
+        self.act = getattr(lin, "activation", None)
+        self.alpha = 1.0
+        self.drop = None
+
+    @property
+    def fusable_grad(self):
+        return self.bn is None and self.act == "lrelu"
+
+
+class Context:
+    """Activation / gradient buffers of one pass at a fixed batch size (caller-owned HBM)."""
+
+    def __init__(self, net, B, device):
+        self.B = B
+        f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
+        self.a0 = f(B, *net.in_shape)
+        self.din = None
+        self.a, self.z, self.keep, self.mean, self.inv, self.dz, self.v = [], [], [], [], [], [], []
+        self.xin: List[Optional[torch.Tensor]] = [None] * len(net.stages)
+        for st in net.stages:
+            self.a.append(f(B, *st.out_shape))
+            self.dz.append(None)
+            self.v.append(None)
+            self.z.append(f(B, *st.out_shape) if st.bn is not None else None)
+            c = st.out_shape[-1]
+            self.mean.append(f(c) if st.bn is not None else None)
+            self.inv.append(f(c) if st.bn is not None else None)
+            self.keep.append(torch.empty((B,) + st.out_shape, dtype=torch.uint8, device=device) if st.drop else None)
+        self._net, self._device = net, device
+        self.dropout_active = False
+
+    def buf(self, lst, i):
+        if lst[i] is None:
+            lst[i] = torch.empty((self.B,) + self._net.stages[i].out_shape, dtype=torch.float32, device=self._device)
+        return lst[i]
+
+    def input_grad(self):
+        if self.din is None:
+            self.din = torch.empty((self.B,) + self._net.in_shape, dtype=torch.float32, device=self._device)
+        return self.din
+
+
+class Net:
+    def __init__(self, flat_layers, store):
+        self.store = store
+        self.device = store.device
+        self.blur = None
+        self.stages: List[Stage] = []
+        self.in_shape = tuple(flat_layers[0][1])
+        cur = None
+        for idx, (l, s) in enumerate(flat_layers):
+            k = l.kind
+            if k == "blur":
+                if idx != 0:
+                    raise NotImplementedError("GaussianBlur2D is only supported as the first layer (blurred_gan.py:31-34)")
+                self.blur = l
+            elif k in ("dense", "conv", "convT"):
+                cur = Stage(l, s)
+                self.stages.append(cur)
+            elif k == "bn":
+                if cur is None or cur.bn is not None or cur.act is not None or cur.drop:
+                    raise NotImplementedError("BatchNormalization must directly follow a linear layer")
+                cur.bn = l
+            elif k == "lrelu":
+                if cur is None or cur.act is not None or cur.drop:
+                    raise NotImplementedError("LeakyReLU must follow a linear layer or its BatchNormalization")
+                cur.act, cur.alpha = "lrelu", l.alpha
+            elif k == "dropout":
+                if cur is None or cur.drop or cur.bn is not None or cur.act != "lrelu":
+                    raise NotImplementedError("Dropout is supported after conv + LeakyReLU (demo_celeba.py:99-121)")
+                cur.drop = l.rate
+            elif k in ("reshape", "flatten"):
+                pass
+            else:
+                raise NotImplementedError(f"layer kind {k!r}")
+        for st in self.stages:
+            if st.kind == "dense" and st.bn is None and st.act is not None:
+                raise NotImplementedError("Dense + activation without BatchNormalization is not on the reference path")
+            if st.act == "tanh" and st.bn is not None:
+                raise NotImplementedError("tanh after BatchNormalization is not on the reference path")
+        self.out_shape = self.stages[-1].out_shape
+        self.conv_layers = [st.lin for st in self.stages if st.kind in ("conv", "convT")]
+        self._ctx = {}
+        self._ws = None
+        self._taps_cache = {}
+        self.rng_offset = 0
+
+    # ------------------------------------------------------------------ resources
+    def context(self, B, tag="default") -> Context:
+        key = (B, tag)
+        if key not in self._ctx:
+            self._ctx[key] = Context(self, B, self.device)
+        return self._ctx[key]
+
+    def workspace(self, nbytes):
+        n = max(int(nbytes), 1024)
+        if self._ws is None or self._ws.numel() * 4 < n:
+            self._ws = torch.empty((n + 3) // 4 + 1024, dtype=torch.float32, device=self.device)
+        return self._ws
+
+    def prepare_weights(self):
+        """(Re)builds the transposed kernel copies the 'other direction' of each conv needs."""
+        self.store.refresh_transposed(self.conv_layers)
+
+    def blur_taps(self, H, W):
+        std = float(self.blur.std)
+        key = (std, H, W)
+        hit = self._taps_cache.get(key)
+        if hit is None:
+            ks, se, nt = ops.blur_policy(std, H, W)
+            taps = ops.gauss_kernel_1d(se, ks)
+            assert len(taps) == nt
+            t = torch.tensor(taps, dtype=torch.float32, device=self.device)
+            if len(self._taps_cache) > 64:
+                self._taps_cache.clear()
+            hit = self._taps_cache[key] = (t, nt)
+        return hit
+
+    def apply_blur(self, x, y):
+        """y = blur(x) with the layer's current std (blurred_gan.py:30; self-adjoint, so also its backward)."""
+        B, H, W, C = x.shape
+        taps, nt = self.blur_taps(H, W)
+        nb = ops.blur_workspace_bytes(B, H, W, C, nt)
+        tmp = self.workspace(nb) if nb else None
+        return ops.blur_nhwc(x, y, taps, nt, tmp)
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, ctx: Context, inputs, training=False, masks=None, seed=0):
+        """inputs: a tensor [B,...] or a list of tensors concatenated along the batch.  ``training`` switches
+        Dropout and BatchNormalization exactly as Keras' ``training=`` argument does."""
+        if self.store.tr_dirty:
+            self.prepare_weights()
+        if not isinstance(inputs, (list, tuple)):
+            inputs = [inputs]
+        B = ctx.B
+        assert sum(int(t.shape[0]) for t in inputs) == B, "batch mismatch"
+        if self.blur is not None:
+            o = 0
+            for t in inputs:
+                n = int(t.shape[0])
+                self.apply_blur(t.view(n, *self.in_shape), ctx.a0[o:o + n])
+                o += n
+            x = ctx.a0
+        elif len(inputs) == 1:
+            x = inputs[0]
+        else:
+            o = 0
+            for t in inputs:
+                n = int(t.shape[0])
+                ctx.a0[o:o + n].copy_(t.view(n, *self.in_shape))
+                o += n
+            x = ctx.a0
+        ctx.dropout_active = bool(training)
+        mi = 0
+        for i, st in enumerate(self.stages):
+            xin = x.view(B, *st.in_shape)
+            ctx.xin[i] = xin
+            out = ctx.a[i]
+            tgt = ctx.z[i] if st.bn is not None else out
+            bias = st.lin.vars.get("bias")
+            keep = None
+            if st.drop:
+                if training:
+                    keep = ctx.keep[i]
+                    if masks is not None:
+                        keep.copy_(masks[mi].view(keep.shape))
+                    else:
+                        ops.keep_mask(keep, 1.0 - st.drop, seed, self.rng_offset)
+                        self.rng_offset += (keep.numel() + 3) // 4
+                mi += 1
+            if st.kind == "dense":
+                K, N = st.in_shape[0], st.out_shape[0]
+                ops.gemm(xin, st.lin.vars["kernel"], tgt, B, N, K, bias=bias)
+            else:
+                if st.bn is not None:
+                    epi = ops.epilogue(EPI_NONE, bias=bias)
+                elif st.act == "lrelu":
+                    epi = ops.epilogue(EPI_BIAS_LRELU, bias=bias, keep=keep, alpha=st.alpha,
+                                       scale=1.0 / (1.0 - st.drop) if st.drop else 1.0)
+                elif st.act == "tanh":
+                    epi = ops.epilogue(EPI_TANH, bias=bias)
+                else:
+                    epi = ops.epilogue(EPI_NONE, bias=bias)
+                if st.kind == "conv":
+                    ops.conv2d_fwd(xin, self.store.transposed_kernel(st.lin), tgt, st.lin.k, st.lin.stride, epi)
+                else:   # Conv2DTranspose forward == data-gradient of the conv with the same kernel array
+                    ops.conv2d_bwd_data(xin, st.lin.vars["kernel"], tgt, st.lin.k, st.lin.stride, epi)
+            if st.bn is not None:
+                C = st.out_shape[-1]
+                M = tgt.numel() // C
+                bn = st.bn
+                if training:
+                    ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
+                    ops.bn_train_fwd(tgt, out, M, C, bn.vars["gamma"], bn.vars["beta"], bn.vars["moving_mean"],
+                                     bn.vars["moving_variance"], ctx.mean[i], ctx.inv[i], ws, eps=bn.epsilon,
+                                     momentum=bn.momentum, unbiased=(len(st.out_shape) == 3), lrelu_alpha=st.alpha)
+                else:
+                    ops.bn_infer_fwd(tgt, out, M, C, bn.vars["gamma"], bn.vars["beta"], bn.vars["moving_mean"],
+                                     bn.vars["moving_variance"], eps=bn.epsilon, lrelu_alpha=st.alpha)
+            x = out
+        return x
+
+    def predict(self, x, training=False):
+        B = int(x.shape[0])
+        ctx = self.context(B, "predict")
+        x = x.to(self.device, torch.float32).contiguous()
+        return self.forward(ctx, x, training=training, seed=np.random.randint(1 << 30)).clone()
+
+    # ------------------------------------------------------------------ backward
+    def backward(self, ctx: Context, dout, need_dx=False, need_dw=True, beta=0.0, scale=1.0):
+        """Reverse pass of the last ``forward`` on ``ctx``.  Weight gradients go to ``store.grad``
+        (= beta*old + scale*new).  Returns d(loss)/d(net input) *before* the blur (or None)."""
+        st_ = self.store
+        if need_dw:
+            st_.ensure_opt_state()
+        B = ctx.B
+        g, g_is_dz = dout, False
+        for i in range(len(self.stages) - 1, -1, -1):
+            st = self.stages[i]
+            gv = g.view(B, *st.out_shape)
+            # ---- through activation / BN -> gradient w.r.t. the linear op's output
+            if st.bn is not None:
+                C = st.out_shape[-1]
+                M = gv.numel() // C
+                dz = ctx.buf(ctx.dz, i)
+                ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
+                dg = st_.grad_of(st.bn, "gamma") if need_dw else torch.empty(C, device=self.device)
+                db = st_.grad_of(st.bn, "beta") if need_dw else torch.empty(C, device=self.device)
+                ops.bn_train_bwd(gv, ctx.a[i], ctx.z[i], dz, M, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], dg, db, ws,
+                                 lrelu_alpha=st.alpha)
+            elif st.act == "lrelu":
+                if g_is_dz:
+                    dz = gv
+                else:
+                    keep = ctx.keep[i] if (st.drop and ctx.dropout_active) else None
+                    dz = ops.mul_grad(gv, ctx.a[i], ctx.buf(ctx.dz, i), keep=keep, alpha=st.alpha,
+                                      scale=1.0 / (1.0 - st.drop) if (st.drop and ctx.dropout_active) else 1.0)
+            elif st.act == "tanh":
+                dz = ops.tanh_bwd(gv, ctx.a[i], ctx.buf(ctx.dz, i))
+            else:
+                dz = gv
+            ctx.dz[i] = dz
+            xin = ctx.xin[i]
+            lin = st.lin
+            # ---- weight gradients
+            if need_dw:
+                dW = st_.grad_of(lin, "kernel")
+                if st.kind == "dense":
+                    K, N = st.in_shape[0], st.out_shape[0]
+                    ops.gemm(xin, dz, dW, K, N, B, transA=True, beta=beta, scale=scale)
+                    rows = B
+                elif st.kind == "conv":
+                    Bc, H, W, Ci = xin.shape
+                    nb = ops.conv2d_bwd_filter_workspace_bytes(Bc, H, W, Ci, lin.filters, lin.k, lin.stride)
+                    ops.conv2d_bwd_filter(xin, dz, dW, lin.k, lin.stride, beta, scale, self.workspace(nb) if nb else None)
+                    rows = dz.numel() // lin.filters
+                else:
+                    Bc, H, W, Ci = dz.shape           # conv input side == ConvT output
+                    nb = ops.conv2d_bwd_filter_workspace_bytes(Bc, H, W, Ci, xin.shape[3], lin.k, lin.stride)
+                    ops.conv2d_bwd_filter(dz, xin, dW, lin.k, lin.stride, beta, scale, self.workspace(nb) if nb else None)
+                    rows = dz.numel() // lin.filters
+                if "bias" in lin.vars:
+                    N = st.out_shape[-1]
+                    ws = self.workspace(ops.colsum_workspace_bytes(rows, N))
+                    ops.colsum(dz, st_.grad_of(lin, "bias"), rows, N, ws, beta=beta, scale=scale)
+            # ---- input gradient
+            if i == 0 and not need_dx:
+                return None
+            prev = self.stages[i - 1] if i > 0 else None
+            fuse = prev is not None and prev.fusable_grad and st.kind != "dense"
+            tgt = ctx.buf(ctx.dz, i - 1).view(B, *st.in_shape) if i > 0 else ctx.input_grad().view(B, *st.in_shape)
+            epi = None
+            if fuse:
+                pk = ctx.keep[i - 1] if (prev.drop and ctx.dropout_active) else None
+                epi = ops.epilogue(EPI_MUL_GRAD, ref=ctx.a[i - 1], keep=pk, alpha=prev.alpha,
+                                   scale=1.0 / (1.0 - prev.drop) if pk is not None else 1.0)
+            if st.kind == "dense":
+                K, N = st.in_shape[0], st.out_shape[0]
+                ops.gemm(dz, lin.vars["kernel"], tgt, B, K, N, transB=True)
+            elif st.kind == "conv":
+                ops.conv2d_bwd_data(dz, lin.vars["kernel"], tgt, lin.k, lin.stride, epi)
+            else:
+                ops.conv2d_fwd(dz, self.store.transposed_kernel(lin), tgt, lin.k, lin.stride, epi)
+            g, g_is_dz = tgt, fuse
+        din = g
+        if self.blur is not None:
+            out = ctx.a0   # forward's blurred input is dead by now; reuse it for blur^T(din)
+            return self.apply_blur(din.view(B, *self.in_shape), out)
+        return din
+
+    # ------------------------------------------------------------------ GP second order
+    def gp_second_order(self, ctx: Context, v0):
+        """SURVEY.md 8a, GP derivation step 2: one linearised forward of the critic on ``v0`` with the
+        LeakyReLU masks of the x-hat pass frozen, plus one wgrad per conv layer against the zeta_i kept by
+        the first-order backward (``ctx.dz``); accumulates into ``store.grad`` (beta = 1)."""
+        st_ = self.store
+        st_.ensure_opt_state()
+        B = ctx.B
+        v = v0
+        for i, st in enumerate(self.stages):
+            lin = st.lin
+            last = i == len(self.stages) - 1
+            if st.kind == "conv" and st.fusable_grad and not last:
+                vin = v.view(B, *st.in_shape)
+                Bc, H, W, Ci = vin.shape
+                nb = ops.conv2d_bwd_filter_workspace_bytes(Bc, H, W, Ci, lin.filters, lin.k, lin.stride)
+                ops.conv2d_bwd_filter(vin, ctx.dz[i], st_.grad_of(lin, "kernel"), lin.k, lin.stride, 1.0, 1.0,
+                                      self.workspace(nb) if nb else None)
+                vo = ctx.buf(ctx.v, i)
+                epi = ops.epilogue(EPI_MUL_GRAD, ref=ctx.a[i], alpha=st.alpha)
+                ops.conv2d_fwd(vin, self.store.transposed_kernel(lin), vo, lin.k, lin.stride, epi)
+                v = vo
+            elif st.kind == "dense" and last and st.out_shape == (1,) and st.bn is None and st.act is None:
+                K = st.in_shape[0]
+                ws = self.workspace(ops.colsum_workspace_bytes(B, K))
+                ops.colsum(v.view(B, K), st_.grad_of(lin, "kernel").view(K), B, K, ws, beta=1.0, scale=1.0)
+            else:
+                raise NotImplementedError("gradient penalty second order supports the reference critic shape only: "
+                                          "[Conv2D+LeakyReLU(+Dropout)]* -> Flatten -> Dense(1) (demo_celeba.py:96-124)")

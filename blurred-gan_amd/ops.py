@@ -1,0 +1,270 @@
+"""Tensor-level wrappers over the C ABI (include/bgan.h).  torch is only the container: every call
+hands raw device pointers + torch's current HIP stream to libbgan_hip.so.  Nothing here computes
+with torch ops, and nothing falls back to the CPU."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import Epilogue, EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, check
+
+LRELU_ALPHA = 0.3
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise BgDeviceError("tensor must live on the GPU (cuda/ROCm device); the HIP path has no CPU fallback")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+class BgDeviceError(RuntimeError):
+    pass
+
+
+def _f32(*ts):
+    for t in ts:
+        if t is not None and t.dtype != torch.float32:
+            raise ValueError(f"expected float32, got {t.dtype}")
+
+
+def same_out(n, s):
+    return -(-n // s)
+
+
+def epilogue(mode=EPI_NONE, bias=None, ref=None, keep=None, alpha=LRELU_ALPHA, scale=1.0):
+    e = Epilogue()
+    e.mode = mode
+    e.bias = bias.data_ptr() if bias is not None else None
+    e.ref = ref.data_ptr() if ref is not None else None
+    e.keep = keep.data_ptr() if keep is not None else None
+    e.alpha, e.scale = alpha, scale
+    e._hold = (bias, ref, keep)      # keep the tensors alive for the duration of the launch call
+    return e
+
+
+# ------------------------------------------------------------------ blur
+def blur_policy(sigma, H, W):
+    ks, se, nt = C.c_float(), C.c_float(), C.c_int()
+    check(_lib.load().bg_blur_policy(float(sigma), H, W, C.byref(ks), C.byref(se), C.byref(nt)), "bg_blur_policy")
+    return ks.value, se.value, nt.value
+
+
+def gauss_kernel_1d(sigma_eff, kernel_size):
+    buf = (C.c_float * 1024)()
+    n = C.c_int()
+    check(_lib.load().bg_gauss_kernel_1d(float(sigma_eff), float(kernel_size), buf, 1024, C.byref(n)), "bg_gauss_kernel_1d")
+    return [buf[i] for i in range(n.value)]
+
+
+def blur_workspace_bytes(B, H, W, Cc, T):
+    return _lib.load().bg_blur_workspace_bytes(B, H, W, Cc, T)
+
+
+def blur_nhwc(x, y, taps_d, n_taps, tmp=None):
+    _f32(x, y, taps_d)
+    B, H, W, Cc = x.shape
+    assert y.shape == x.shape and taps_d.numel() >= n_taps
+    check(_lib.load().bg_blur_nhwc_f32(_ptr(x), _ptr(y), B, H, W, Cc, _ptr(taps_d), n_taps, _ptr(tmp), _stream()), "bg_blur_nhwc_f32")
+    return y
+
+
+# ------------------------------------------------------------------ conv family
+def conv2d_fwd(x, wT, y, ksize, stride, epi=None):
+    """x [B,H,W,Cin], wT [k*k,Cout,Cin] -> y [B,Ho,Wo,Cout]."""
+    _f32(x, wT, y)
+    B, H, W, Cin = x.shape
+    Cout = y.shape[3]
+    assert wT.numel() == ksize * ksize * Cin * Cout, (wT.shape, Cin, Cout)
+    assert tuple(y.shape) == (B, same_out(H, stride), same_out(W, stride), Cout), (x.shape, y.shape)
+    check(_lib.load().bg_conv2d_fwd(_ptr(x), _ptr(wT), _ptr(y), B, H, W, Cin, Cout, ksize, stride,
+                                    C.byref(epi) if epi is not None else None, _stream()), "bg_conv2d_fwd")
+    return y
+
+
+def conv2d_bwd_data(dy, w, dx, ksize, stride, epi=None):
+    """dy [B,Ho,Wo,Cout], w [k*k,Cin,Cout] -> dx [B,H,W,Cin]."""
+    _f32(dy, w, dx)
+    B, H, W, Cin = dx.shape
+    Cout = dy.shape[3]
+    assert w.numel() == ksize * ksize * Cin * Cout
+    assert tuple(dy.shape) == (B, same_out(H, stride), same_out(W, stride), Cout), (dy.shape, dx.shape)
+    check(_lib.load().bg_conv2d_bwd_data(_ptr(dy), _ptr(w), _ptr(dx), B, H, W, Cin, Cout, ksize, stride,
+                                         C.byref(epi) if epi is not None else None, _stream()), "bg_conv2d_bwd_data")
+    return dx
+
+
+def conv2d_bwd_filter_workspace_bytes(B, H, W, Cin, Cout, ksize, stride):
+    return _lib.load().bg_conv2d_bwd_filter_workspace_bytes(B, H, W, Cin, Cout, ksize, stride)
+
+
+def conv2d_bwd_filter(x, dy, dw, ksize, stride, beta=0.0, scale=1.0, ws=None):
+    """x [B,H,W,Cin], dy [B,Ho,Wo,Cout] -> dw [k,k,Cin,Cout] = beta*dw + scale*grad."""
+    _f32(x, dy, dw)
+    B, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    assert dw.numel() == ksize * ksize * Cin * Cout
+    assert tuple(dy.shape[:3]) == (B, same_out(H, stride), same_out(W, stride))
+    wsb = ws.numel() * ws.element_size() if ws is not None else 0
+    check(_lib.load().bg_conv2d_bwd_filter(_ptr(x), _ptr(dy), _ptr(dw), B, H, W, Cin, Cout, ksize, stride, beta, scale,
+                                           _ptr(ws), wsb, _stream()), "bg_conv2d_bwd_filter")
+    return dw
+
+
+def transpose_last2(src, dst, T, R, Cc):
+    _f32(src, dst)
+    assert src.numel() == T * R * Cc == dst.numel()
+    check(_lib.load().bg_transpose_last2(_ptr(src), _ptr(dst), T, R, Cc, _stream()), "bg_transpose_last2")
+    return dst
+
+
+# ------------------------------------------------------------------ dense / reductions / BN
+def gemm(A, Bm, Cm, M, N, K, transA=False, transB=False, bias=None, beta=0.0, scale=1.0):
+    _f32(A, Bm, Cm, bias)
+    assert A.numel() == M * K and Bm.numel() == K * N and Cm.numel() == M * N
+    check(_lib.load().bg_gemm_f32(_ptr(A), _ptr(Bm), _ptr(Cm), M, N, K, int(transA), int(transB), _ptr(bias), beta, scale,
+                                  _stream()), "bg_gemm_f32")
+    return Cm
+
+
+def colsum_workspace_bytes(M, N):
+    return _lib.load().bg_colsum_workspace_bytes(M, N)
+
+
+def colsum(x, out, M, N, ws, square=False, beta=0.0, scale=1.0):
+    _f32(x, out)
+    assert x.numel() == M * N and out.numel() == N
+    check(_lib.load().bg_colsum_f32(_ptr(x), _ptr(out), M, N, int(square), beta, scale, _ptr(ws),
+                                    ws.numel() * ws.element_size(), _stream()), "bg_colsum_f32")
+    return out
+
+
+def bn_train_fwd(x, y, M, Cc, gamma, beta, moving_mean, moving_var, save_mean, save_inv, ws, eps=1e-3, momentum=0.99,
+                 unbiased=True, lrelu_alpha=LRELU_ALPHA):
+    _f32(x, y, gamma, beta, save_mean, save_inv)
+    assert x.numel() == M * Cc == y.numel()
+    check(_lib.load().bg_bn_train_fwd(_ptr(x), _ptr(y), M, Cc, _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var),
+                                      _ptr(save_mean), _ptr(save_inv), eps, momentum, int(unbiased), lrelu_alpha, _ptr(ws),
+                                      ws.numel() * ws.element_size(), _stream()), "bg_bn_train_fwd")
+    return y
+
+
+def bn_infer_fwd(x, y, M, Cc, gamma, beta, moving_mean, moving_var, eps=1e-3, lrelu_alpha=LRELU_ALPHA):
+    _f32(x, y)
+    assert x.numel() == M * Cc == y.numel()
+    check(_lib.load().bg_bn_infer_fwd(_ptr(x), _ptr(y), M, Cc, _ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var),
+                                      eps, lrelu_alpha, _stream()), "bg_bn_infer_fwd")
+    return y
+
+
+def bn_train_bwd(dy, y, x, dx, M, Cc, gamma, save_mean, save_inv, dgamma, dbeta, ws, lrelu_alpha=LRELU_ALPHA):
+    _f32(dy, y, x, dx)
+    assert dy.numel() == M * Cc == dx.numel()
+    check(_lib.load().bg_bn_train_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(dx), M, Cc, _ptr(gamma), _ptr(save_mean), _ptr(save_inv),
+                                      _ptr(dgamma), _ptr(dbeta), lrelu_alpha, _ptr(ws), ws.numel() * ws.element_size(),
+                                      _stream()), "bg_bn_train_bwd")
+    return dx
+
+
+# ------------------------------------------------------------------ pointwise / losses / adam / rng
+def lerp(r, f, alpha_b, out):
+    B = r.shape[0]
+    n_per = r.numel() // B
+    check(_lib.load().bg_lerp_f32(_ptr(r), _ptr(f), _ptr(alpha_b), _ptr(out), B, n_per, _stream()), "bg_lerp_f32")
+    return out
+
+
+def row_norm(g, out_b):
+    B = g.shape[0]
+    check(_lib.load().bg_row_norm_f32(_ptr(g), _ptr(out_b), B, g.numel() // B, _stream()), "bg_row_norm_f32")
+    return out_b
+
+
+def gp_seed(g, norm_b, coef, out):
+    B = g.shape[0]
+    check(_lib.load().bg_gp_seed_f32(_ptr(g), _ptr(norm_b), coef, _ptr(out), B, g.numel() // B, _stream()), "bg_gp_seed_f32")
+    return out
+
+
+def mul_grad(d, ref, out, keep=None, alpha=LRELU_ALPHA, scale=1.0):
+    assert d.numel() == ref.numel() == out.numel()
+    check(_lib.load().bg_mul_grad_f32(_ptr(d), _ptr(ref), _ptr(keep), alpha, scale, _ptr(out), d.numel(), _stream()), "bg_mul_grad_f32")
+    return out
+
+
+def tanh_bwd(dy, y, out):
+    check(_lib.load().bg_tanh_bwd_f32(_ptr(dy), _ptr(y), _ptr(out), dy.numel(), _stream()), "bg_tanh_bwd_f32")
+    return out
+
+
+def outer(s_b, w_k, out):
+    B, K = s_b.numel(), w_k.numel()
+    assert out.numel() == B * K
+    check(_lib.load().bg_outer_f32(_ptr(s_b), _ptr(w_k), _ptr(out), B, K, _stream()), "bg_outer_f32")
+    return out
+
+
+def fill(x, v):
+    check(_lib.load().bg_fill_f32(_ptr(x), float(v), x.numel(), _stream()), "bg_fill_f32")
+    return x
+
+
+def scale_(x, v):
+    check(_lib.load().bg_scale_f32(_ptr(x), float(v), x.numel(), _stream()), "bg_scale_f32")
+    return x
+
+
+def wgangp_d_loss(fs, rs, norm_b, inv_gbs, gp_coef, e_drift, vec_scale, dfs, drs, metrics):
+    B = fs.numel()
+    check(_lib.load().bg_wgangp_d_loss(_ptr(fs), _ptr(rs), _ptr(norm_b), B, inv_gbs, gp_coef, e_drift, vec_scale, _ptr(dfs),
+                                       _ptr(drs), _ptr(metrics), _stream()), "bg_wgangp_d_loss")
+
+
+def wgan_g_loss(s, inv_gbs, ds, metrics):
+    check(_lib.load().bg_wgan_g_loss(_ptr(s), s.numel(), inv_gbs, _ptr(ds), _ptr(metrics), _stream()), "bg_wgan_g_loss")
+
+
+def adam(theta, m, v, g, lr_t, b1=0.9, b2=0.999, eps=1e-7):
+    assert theta.numel() == m.numel() == v.numel() == g.numel()
+    check(_lib.load().bg_adam_f32(_ptr(theta), _ptr(m), _ptr(v), _ptr(g), theta.numel(), lr_t, b1, b2, eps, _stream()), "bg_adam_f32")
+
+
+def uniform(out, seed, offset=0):
+    check(_lib.load().bg_uniform_f32(_ptr(out), out.numel(), seed, offset, _stream()), "bg_uniform_f32")
+    return out
+
+
+def keep_mask(out, keep_prob, seed, offset=0):
+    assert out.dtype == torch.uint8
+    check(_lib.load().bg_keep_mask_u8(_ptr(out), out.numel(), keep_prob, seed, offset, _stream()), "bg_keep_mask_u8")
+    return out
+
+
+# ------------------------------------------------------------------ profiling
+def prof_enable(on):
+    _lib.load().bg_prof_enable(int(on))
+
+
+def prof_reset():
+    _lib.load().bg_prof_reset()
+
+
+def prof_records():
+    lib = _lib.load()
+    n = lib.bg_prof_count()
+    out = []
+    name = C.create_string_buffer(128)
+    ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+    for i in range(n):
+        check(lib.bg_prof_get(i, name, 128, C.byref(ms), C.byref(fl), C.byref(by)), "bg_prof_get")
+        out.append((name.value.decode(), ms.value, fl.value, by.value))
+    return out

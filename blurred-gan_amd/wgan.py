@@ -1,0 +1,436 @@
+"""Mirror of reference wgan.py: ``WGAN``, ``WGANGP``, ``gradient_penalty``, ``TrainingConfig`` with the same
+constructor, attributes and method names, executing on the HIP kernels (no tape, no torch autograd).
+
+Step order, training flags and loss algebra follow wgan.py:86-172, 234-285 including its quirks
+(SURVEY.md 8a Q1, Q2, Q4, Q6); each quirk that changes numbers is a named constructor switch.
+"""
+from __future__ import annotations
+
+import math
+import os
+from contextlib import contextmanager
+from dataclasses import dataclass
+from typing import List
+
+import numpy as np
+import torch
+
+from . import dist, ops
+from .gaussian_blur import Variable
+from .layers import Sequential, get_seed
+from .utils import JsonSerializable, ParseableFromCommandLine
+
+ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7       # tf.keras.optimizers.Adam defaults (wgan.py:56)
+
+
+@dataclass
+class TrainingConfig(JsonSerializable, ParseableFromCommandLine):
+    """Parameters related to the training configuration of the Model (wgan.py:19-25)."""
+    log_dir: str = "results/log"
+    checkpoint_dir: str = "results/log/checkpoints"
+    save_image_summaries_interval: int = 50
+
+
+class Mean:
+    """tf.keras.metrics.Mean stand-in (host side)."""
+
+    def __init__(self, name, dtype=None):
+        self.name = name
+        self.reset_states()
+
+    def reset_states(self):
+        self.total, self.count = 0.0, 0
+
+    def __call__(self, value, weight=1):
+        self.total += float(value) * weight
+        self.count += weight
+
+    update_state = __call__
+
+    def result(self):
+        return self.total / self.count if self.count else 0.0
+
+
+class _Adam:
+    """Keras Adam bookkeeping; the update itself is one fused launch over the model's flat buffer."""
+
+    def __init__(self, learning_rate=0.001):
+        self.learning_rate = learning_rate
+        self.iterations = 0
+
+    def apply(self, store):
+        self.iterations += 1
+        t = self.iterations
+        lr_t = float(self.learning_rate) * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+        ops.adam(store.theta[:store.n_train], store.m[:store.n_train], store.v[:store.n_train],
+                 store.grad[:store.n_train], lr_t, ADAM_B1, ADAM_B2, ADAM_EPS)
+        store.tr_dirty = True
+
+
+class _SummaryWriter:
+    """Very small stand-in for tf.summary's file writer: scalars appended to <log_dir>/scalars.jsonl."""
+
+    def __init__(self, log_dir):
+        self.log_dir = log_dir
+        self._fh = None
+
+    @contextmanager
+    def as_default(self):
+        yield self
+
+    def scalar(self, name, value, step=None):
+        import json
+        if self._fh is None:
+            os.makedirs(self.log_dir, exist_ok=True)
+            self._fh = open(os.path.join(self.log_dir, "scalars.jsonl"), "a")
+        self._fh.write(json.dumps({"name": name, "value": float(value), "step": None if step is None else int(step)}) + "\n")
+        self._fh.flush()
+
+
+class WGAN:
+    """Wasserstein GAN (wgan.py:28-231)."""
+
+    @dataclass
+    class HyperParameters(JsonSerializable, ParseableFromCommandLine):
+        """Dataclass containing the hyperparameters of the Model (wgan.py:34-43)."""
+        learning_rate: float = 0.001
+        d_steps_per_g_step: int = 1
+        batch_size: int = 32
+        global_batch_size: int = 32
+        optimizer: str = "adam"
+
+    uses_gradient_penalty = False
+
+    def __init__(self, generator: Sequential, discriminator: Sequential, hyperparams: "WGAN.HyperParameters",
+                 config: TrainingConfig, *args, reproduce_vector_loss_quirk: bool = True, sync_metrics: bool = True, **kwargs):
+        self.hparams = hyperparams
+        if str(self.hparams.optimizer).lower() != "adam":
+            raise NotImplementedError("only the reference's default optimizer 'adam' is implemented (wgan.py:43,56)")
+        self.generator = generator
+        self.generator.build()
+        self.generator.optimizer = _Adam(self.hparams.learning_rate)
+        self.discriminator = discriminator
+        self.discriminator.build()
+        self.discriminator.optimizer = _Adam(self.hparams.learning_rate)
+        self.d_steps_per_g_step = self.hparams.d_steps_per_g_step
+        self.batch_size = None
+        self.config = config
+        self.summary_writer = _SummaryWriter(config.log_dir)
+        self.n_img = Variable(0, name="n_img", dtype=int)
+        self.n_batches = Variable(0, name="n_batches", dtype=int)
+        self.real_scores_metric = Mean("real_scores")
+        self.fake_scores_metric = Mean("fake_scores")
+        self.gen_loss_metric = Mean("gen_loss")
+        self.disc_loss_metric = Mean("disc_loss")
+        self.optimizer = "unused"
+        self.stop_training = False
+        self.images = None
+        # --- build-side switches (documented in DESIGN.md)
+        self.reproduce_vector_loss_quirk = reproduce_vector_loss_quirk
+        self.sync_metrics = sync_metrics     # False: skip the per-step device->host metric read (bench)
+        self._rng_seed = get_seed()
+        self._rng_off = 0
+        self._bufs = {}
+        self._injected = None
+
+    # ------------------------------------------------------------------ small helpers
+    @property
+    def device(self):
+        return self.generator.store.device
+
+    @property
+    def latent_size(self):
+        return self.generator.input_shape[-1]
+
+    @property
+    def metrics(self) -> List[Mean]:
+        return [self.real_scores_metric, self.fake_scores_metric, self.gen_loss_metric, self.disc_loss_metric]
+
+    @property
+    def metrics_names(self):
+        return ["loss"] + [m.name for m in self.metrics]
+
+    def reset_metrics(self):
+        for m in self.metrics:
+            m.reset_states()
+
+    def _buf(self, name, shape, dtype=torch.float32):
+        key = (name, tuple(shape), dtype)
+        b = self._bufs.get(key)
+        if b is None:
+            b = self._bufs[key] = torch.empty(*shape, dtype=dtype, device=self.device)
+        return b
+
+    def _uniform(self, name, shape):
+        """tf.random.uniform stand-in (wgan.py:118,237): own counter-based stream, seed + rank."""
+        out = self._buf(name, shape)
+        ops.uniform(out, self._rng_seed + 7919 * dist.rank(), self._rng_off)
+        self._rng_off += (out.numel() + 3) // 4
+        return out
+
+    def _inj(self, key):
+        return None if self._injected is None else self._injected.get(key)
+
+    def _vec_scale(self, B):
+        """Q1: the reference adds a [B] drift vector to the scalar loss, and GradientTape sums it, which
+        multiplies the Wasserstein and GP gradients by the (global) batch size (wgan.py:279-285)."""
+        return float(B * dist.world_size()) if (self.uses_gradient_penalty and self.reproduce_vector_loss_quirk) else 1.0
+
+    # ------------------------------------------------------------------ reference API
+    def train_on_batch(self, reals, *args, randomness=None, **kwargs):
+        """wgan.py:86-114.  ``randomness`` (build-side, for parity tests) injects the step's random inputs:
+        dict(z_d, z_g, alpha, mask_fake, mask_real)."""
+        self.reset_metrics()
+        reals = self._as_device(reals)
+        self.batch_size = int(reals.shape[0])
+        self._injected = randomness
+        try:
+            disc_loss, self.images = self.discriminator_step(reals)
+            if int(self.n_batches) % self.d_steps_per_g_step == 0:
+                self.generator_step()
+        finally:
+            self._injected = None
+        self.log_image_summaries()
+        self.n_img.assign_add(self.batch_size)
+        self.n_batches.assign_add(1)
+        return self._organize_metrics()
+
+    def _as_device(self, x):
+        if isinstance(x, np.ndarray):
+            x = torch.from_numpy(x)
+        return x.to(self.device, torch.float32).contiguous()
+
+    def latents_batch(self):
+        assert self.batch_size is not None
+        return self._uniform("latents", (self.batch_size, self.latent_size))
+
+    def generate_samples(self, latents=None, training=False):
+        if latents is None:
+            if self.batch_size is None:
+                self.batch_size = self.hparams.batch_size
+            latents = self.latents_batch()
+        latents = self._as_device(latents)
+        G = self.generator.net()
+        ctx = G.context(int(latents.shape[0]), "g")
+        return G.forward(ctx, latents, training=training)
+
+    # ---- discriminator
+    def discriminator_loss(self, reals, fakes, real_scores, fake_scores):
+        """wgan.py:128-130 (value only; the training step uses the fused device path)."""
+        return (fake_scores - real_scores).sum() * (1.0 / self.hparams.global_batch_size)
+
+    def discriminator_step(self, reals):
+        """wgan.py:132-151."""
+        reals = self._as_device(reals)
+        B = int(reals.shape[0])
+        self.batch_size = B
+        hp = self.hparams
+        G, D = self.generator.net(), self.discriminator.net()
+        z = self._inj("z_d")
+        z = self._as_device(z) if z is not None else self._uniform("z_d", (B, self.latent_size))
+        fakes = G.forward(G.context(B, "g_dstep"), z, training=False)           # Q4: inference BN in the D-step
+        cfr = D.context(2 * B, "fr")
+        masks = None
+        if self._inj("mask_fake") is not None:
+            masks = [torch.cat([self._as_mask(a), self._as_mask(b)], 0)
+                     for a, b in zip(self._inj("mask_fake"), self._inj("mask_real"))]
+        s2 = D.forward(cfr, [fakes, reals], training=True, masks=masks, seed=self._rng_seed + 104729 * (dist.rank() + 1)).view(2 * B)
+        fs, rs = s2[:B], s2[B:]
+        inv_gbs = 1.0 / float(hp.global_batch_size)
+        norms = g = None
+        if self.uses_gradient_penalty:
+            norms, g = self._gp_first_order(reals, fakes)
+        ds2 = self._buf("ds2", (2 * B,))
+        met = self._buf("d_metrics", (8,))
+        vs = self._vec_scale(B)
+        ops.wgangp_d_loss(fs, rs, norms, inv_gbs, float(getattr(hp, "gp_coefficient", 0.0)) if self.uses_gradient_penalty else 0.0,
+                          float(getattr(hp, "e_drift", 0.0)) if self.uses_gradient_penalty else 0.0, vs, ds2[:B], ds2[B:], met)
+        D.backward(cfr, ds2.view(2 * B, 1), need_dx=False, need_dw=True, beta=0.0, scale=1.0)
+        if self.uses_gradient_penalty:
+            # d/dW of vec_scale * gp_coefficient * mean_global((n-1)^2): seed carries the whole factor
+            coef = vs * float(hp.gp_coefficient) * 2.0 / float(B * dist.world_size())
+            gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)))
+            chat = D.context(B, "hat")
+            v0 = D.apply_blur(gbar, self._buf("v0", tuple(g.shape))) if D.blur is not None else gbar
+            D.gp_second_order(chat, v0)
+        store = self.discriminator.store
+        dist.all_reduce_sum_(store.grad[:store.n_train])
+        self.discriminator.optimizer.apply(store)
+        self._d_metrics_dev = met
+        if self.sync_metrics:
+            m = met.cpu().tolist()
+            self.fake_scores_metric(m[0])
+            self.real_scores_metric(m[1])
+            self.disc_loss_metric(m[2])
+            self._record_gp_metrics(m)
+            disc_loss = m[2]
+        else:
+            disc_loss = None
+        return disc_loss, (fakes, reals)
+
+    def _record_gp_metrics(self, m):
+        pass
+
+    @staticmethod
+    def _as_mask(a):
+        if isinstance(a, np.ndarray):
+            a = torch.from_numpy(a)
+        return a.to(torch.uint8)
+
+    def _gp_first_order(self, reals, fakes):
+        """wgan.py:234-245 on the device: x_hat, critic forward (training=False), gradient w.r.t. x_hat
+        (through blur^T), per-sample L2 norms.  Leaves zeta_i in the 'hat' context for the second order."""
+        B = int(reals.shape[0])
+        D = self.discriminator.net()
+        a = self._inj("alpha")
+        a = self._as_device(a).view(B) if a is not None else self._uniform("alpha", (B,))
+        xhat = ops.lerp(reals, fakes, a, self._buf("xhat", tuple(reals.shape)))
+        chat = D.context(B, "hat")
+        D.forward(chat, xhat, training=False)
+        ones = ops.fill(self._buf("ones", (B, 1)), 1.0)
+        g = D.backward(chat, ones, need_dx=True, need_dw=False)
+        norms = ops.row_norm(g, self._buf("gp_norms", (B,)))
+        return norms, g
+
+    # ---- generator
+    def generator_loss(self, fake_scores):
+        """wgan.py:155-157."""
+        return -fake_scores.sum() * (1.0 / self.hparams.global_batch_size)
+
+    def generator_step(self):
+        """wgan.py:159-172."""
+        B = self.batch_size
+        G, D = self.generator.net(), self.discriminator.net()
+        z = self._inj("z_g")
+        z = self._as_device(z) if z is not None else self._uniform("z_g", (B, self.latent_size))
+        cg = G.context(B, "g")
+        fakes = G.forward(cg, z, training=True)
+        chat = D.context(B, "hat")
+        s = D.forward(chat, fakes, training=False).view(B)
+        ds = self._buf("ds_g", (B,))
+        met = self._buf("g_metrics", (4,))
+        ops.wgan_g_loss(s, 1.0 / float(self.hparams.global_batch_size), ds, met)
+        dfakes = D.backward(chat, ds.view(B, 1), need_dx=True, need_dw=False)
+        G.backward(cg, dfakes, need_dx=False, need_dw=True, beta=0.0, scale=1.0)
+        store = self.generator.store
+        dist.all_reduce_sum_(store.grad[:store.n_train])
+        self.generator.optimizer.apply(store)
+        self._g_metrics_dev = met
+        if self.sync_metrics:
+            m = met.cpu().tolist()
+            self.fake_scores_metric(m[0])                      # Q6: second update of the same Mean
+            self.gen_loss_metric(m[1])
+            return m[1]
+        return None
+
+    # ---- bookkeeping / Keras surface
+    def log_image_summaries(self):
+        """wgan.py:176-180: image summaries are a TensorBoard feature; not written by this build."""
+        return None
+
+    def _organize_metrics(self) -> List[float]:
+        """wgan.py:182-200: [0.0] + metric results in metrics_names order."""
+        by_name = {m.name: m for m in self.metrics}
+        assert len(by_name) == len(self.metrics), "duplicate metric names"
+        return [0.0] + [by_name[n].result() for n in self.metrics_names if n != "loss"]
+
+    @contextmanager
+    def record_image_summaries(self):
+        yield
+
+    def summary(self):
+        print("Discriminator:")
+        self.discriminator.summary()
+        print("Generator:")
+        self.generator.summary()
+        print(f"Total params: {self.count_params():,}")
+
+    def count_params(self):
+        return self.discriminator.count_params() + self.generator.count_params()
+
+    def save_weights(self, filepath, overwrite=True, save_format=None):
+        """wgan.py:229-231."""
+        self.discriminator.save_weights(filepath + "_discriminator", overwrite, save_format)
+        self.generator.save_weights(filepath + "_generator", overwrite, save_format)
+
+    def fit(self, x, y=None, epochs=1, initial_epoch=0, callbacks=None, steps_per_epoch=None, verbose=0):
+        """The slice of ``tf.keras.Model.fit`` the reference demos rely on (demo_mnist.py:187-206): iterate
+        batches, call the Keras callback hooks around ``train_on_batch``, honour ``stop_training``."""
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            if hasattr(cb, "set_model"):
+                cb.set_model(self)
+            else:
+                cb.model = self
+        call = lambda name, *a: [getattr(cb, name)(*a) for cb in callbacks if hasattr(cb, name)]
+        call("on_train_begin", {})
+        history = []
+        for epoch in range(int(initial_epoch), int(epochs)):
+            call("on_epoch_begin", epoch, {})
+            logs = {}
+            for batch, reals in enumerate(x):
+                if steps_per_epoch is not None and batch >= steps_per_epoch:
+                    break
+                size = int(reals.shape[0])
+                call("on_batch_begin", batch, {"batch": batch, "size": size})
+                values = self.train_on_batch(reals)
+                logs = {"batch": batch, "size": size}
+                logs.update(dict(zip(self.metrics_names, values)))
+                call("on_batch_end", batch, logs)
+                if self.stop_training:
+                    break
+            history.append(dict(logs))
+            call("on_epoch_end", epoch, logs)
+            if self.stop_training:
+                break
+        call("on_train_end", {})
+        return history
+
+
+def gradient_penalty(discriminator, reals, fakes, alpha=None):
+    """wgan.py:234-246 (value only): mean((||d D(x_hat)/d x_hat|| - 1)^2) on the HIP kernels."""
+    D = discriminator.net()
+    dev = D.device
+    reals = reals.to(dev, torch.float32).contiguous()
+    fakes = fakes.to(dev, torch.float32).contiguous()
+    B = int(reals.shape[0])
+    if alpha is None:
+        alpha = ops.uniform(torch.empty(B, dtype=torch.float32, device=dev), get_seed() + 17, np.random.randint(1 << 30))
+    xhat = ops.lerp(reals, fakes, alpha.to(dev, torch.float32).contiguous().view(B), torch.empty_like(reals))
+    ctx = D.context(B, "gp_fn")
+    D.forward(ctx, xhat, training=False)
+    g = D.backward(ctx, ops.fill(torch.empty(B, 1, dtype=torch.float32, device=dev), 1.0), need_dx=True, need_dw=False)
+    n = ops.row_norm(g, torch.empty(B, dtype=torch.float32, device=dev))
+    return ((n - 1.0) ** 2).mean()
+
+
+class WGANGP(WGAN):
+    """Wasserstein GAN with Gradient Penalty loss (wgan.py:249-285)."""
+
+    @dataclass
+    class HyperParameters(WGAN.HyperParameters):
+        """Hyperparameters of a WGAN model with Gradient Penalty loss (wgan.py:255-261)."""
+        e_drift: float = 1e-4
+        gp_coefficient: float = 10.0
+
+    uses_gradient_penalty = True
+
+    def __init__(self, generator, discriminator, hyperparams, config, *args, **kwargs):
+        super().__init__(generator, discriminator, hyperparams, config, *args, **kwargs)
+        self.gp_term_metric = Mean("gp_term")
+        self.norm_term_metric = Mean("norm_term")
+
+    @property
+    def metrics(self):
+        return super().metrics + [self.gp_term_metric, self.norm_term_metric]
+
+    def _record_gp_metrics(self, m):
+        self.gp_term_metric(m[3])
+        self.norm_term_metric(m[4])
+
+    def discriminator_loss(self, reals, fakes, real_scores, fake_scores):
+        """wgan.py:272-285 (value only): a [B] vector, as in the reference."""
+        loss = super().discriminator_loss(reals, fakes, real_scores, fake_scores)
+        gp_term = self.hparams.gp_coefficient * gradient_penalty(self.discriminator, reals, fakes)
+        norm_term = self.hparams.e_drift * (fake_scores.abs().view(-1) + real_scores.abs().view(-1))
+        return loss + gp_term + norm_term

@@ -1,0 +1,175 @@
+/*
+ * bgan.h -- C ABI of libbgan_hip.so: the MI355X (gfx950) kernels behind blurred-GAN's
+ * WGAN-GP training step.
+ *
+ * The reference (lebrice/blurred-GAN) has no FFI seam of its own: its hot path is Python that
+ * calls TensorFlow ops.  This header is the seam the build introduces: one
+ * extern "C" entry point per TF op family the reference's step invokes, each citing the
+ * reference call site it replaces.  Conventions:
+ *
+ *   - every pointer named *_d / typed `const float*` etc. is a raw DEVICE address (HBM); the caller
+ *     (Python via torch.Tensor.data_ptr()) owns every buffer including workspaces; the library
+ *     keeps no device memory between calls;
+ *   - tensors are dense NHWC float32; Conv2D kernels are [kh,kw,Cin,Cout], Conv2DTranspose kernels
+ *     [kh,kw,Cout,Cin], Dense kernels [in,out] -- exactly as TF/Keras stores them;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream); launches are
+ *     asynchronous, nothing synchronises the device;
+ *   - every function returns 0 on success or a negative bg_status; bg_last_error() gives the
+ *     thread-local message; nothing aborts or throws across the boundary.
+ */
+#ifndef BGAN_H
+#define BGAN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BG_ABI_VERSION 1
+
+typedef enum {
+  BG_OK = 0,
+  BG_ERR_BAD_SHAPE = -1,      /* non-positive / inconsistent dimensions                       */
+  BG_ERR_BAD_ALIGNMENT = -2,  /* pointer not aligned as the kernel requires (16 B)             */
+  BG_ERR_UNSUPPORTED = -3,    /* valid request this build has no kernel for                    */
+  BG_ERR_HIP = -4,            /* a HIP runtime call failed (message has hipGetErrorString)     */
+  BG_ERR_WORKSPACE = -5,      /* workspace missing or too small (see *_workspace_bytes)        */
+  BG_ERR_NULL = -6            /* required pointer is NULL                                      */
+} bg_status;
+
+/* ---- meta ------------------------------------------------------------------------------- */
+int bg_version(void);
+const char* bg_last_error(void);
+const char* bg_status_string(int status);
+
+/* ---- profiling hooks (bench.py roofline: per-kernel HIP-event timing on the launch stream) */
+int bg_prof_enable(int on);                       /* record an event pair around every launch */
+int bg_prof_reset(void);
+int bg_prof_count(void);                          /* synchronises the recorded events          */
+int bg_prof_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes);
+
+/* ---- Gaussian blur: gaussian_blur.py:15-132 ---------------------------------------------- */
+/* gaussian_blur.py:21-31,58-72 (appropriate_kernel_size, appropriate_std, clip, max): host maths, float32. */
+int bg_blur_policy(float sigma, int H, int W, float* kernel_size, float* sigma_eff, int* n_taps);
+/* gaussian_blur.py:83-88 (gaussian_kernel_1d): writes n_taps float32 weights to HOST memory. */
+int bg_gauss_kernel_1d(float sigma_eff, float kernel_size, float* taps_host, int cap, int* n_taps);
+/* gaussian_blur.py:91-132 (two tf.nn.depthwise_conv2d, SAME, zero padding): y = blur(x), NHWC.
+ * taps_d: n_taps device floats.  tmp_d: scratch of the same size as x (may be NULL when the whole
+ * image fits the fused kernel, see bg_blur_workspace_bytes).  The op is self-adjoint, so the same
+ * call is its own backward. */
+size_t bg_blur_workspace_bytes(int B, int H, int W, int C, int n_taps);
+int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C,
+                     const float* taps_d, int n_taps, float* tmp_d, void* stream);
+
+/* ---- convolution family: layers.Conv2D / Conv2DTranspose (demo_celeba.py:62-119,
+ *      demo_mnist.py:60-81) and their tape gradients (wgan.py:140,166,244) -------------------
+ * Geometry is TF 'SAME' for a kxk kernel (k odd, k*k <= 25), stride 1 or 2:
+ *   Ho = ceil(H/s), pad_total = max((Ho-1)s + k - H, 0), pad_before = pad_total/2.
+ * H, W, Cin always describe the conv's INPUT side, Ho/Wo/Cout its OUTPUT side, also for the
+ * backward calls.  A Conv2DTranspose with kernel [k,k,Cout_t,Cin_t] is the data-gradient of the
+ * conv whose kernel is that same array read as [k,k,Cin=Cout_t,Cout=Cin_t]; call bg_conv2d_bwd_data
+ * for its forward, bg_conv2d_fwd for its data-gradient, bg_conv2d_bwd_filter(x := dy_t, dy := x_t)
+ * for its filter-gradient.
+ *
+ * Weight operand layout expected by the MFMA kernels is "NK": [tap][n][k] with the contraction
+ * index k contiguous.  For bg_conv2d_bwd_data that IS the TF layout [kh,kw,Cin,Cout]; for
+ * bg_conv2d_fwd it is the last-two-dims transpose [kh,kw,Cout,Cin] (bg_transpose_last2 makes it).
+ */
+typedef enum {
+  BG_EPI_NONE = 0,        /* y = acc (+ bias)                                                   */
+  BG_EPI_BIAS_LRELU = 1,  /* y = lrelu(acc + bias); then y *= keep ? scale : 0 when keep != NULL */
+  BG_EPI_MUL_GRAD = 2,    /* y = acc * (ref > 0 ? 1 : alpha) [* keep ? scale : 0]               */
+  BG_EPI_TANH = 3         /* y = tanh(acc + bias)                                               */
+} bg_epi_mode;
+
+typedef struct {
+  int mode;               /* bg_epi_mode                                                        */
+  const float* bias;      /* [Cout] or NULL                                                     */
+  const float* ref;       /* BG_EPI_MUL_GRAD: activation whose sign selects 1 / alpha, same shape as y */
+  const uint8_t* keep;    /* dropout keep mask (1 = kept), same shape as y, or NULL             */
+  float alpha;            /* LeakyReLU slope (Keras default 0.3)                                */
+  float scale;            /* 1 / keep_prob                                                      */
+} bg_epilogue;
+
+/* y[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w) ; wT_d = [k*k][Cout][Cin] */
+int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int W, int Cin, int Cout,
+                  int ksize, int stride, const bg_epilogue* epi, void* stream);
+/* dx[B,H,W,Cin] = conv^T(dy[B,Ho,Wo,Cout], w) ; w_d = [k*k][Cin][Cout] (TF Conv2D layout) */
+int bg_conv2d_bwd_data(const float* dy, const float* w_d, float* dx, int B, int H, int W, int Cin, int Cout,
+                       int ksize, int stride, const bg_epilogue* epi, void* stream);
+/* dw[k,k,Cin,Cout] = beta*dw + scale * sum_pixels x (x) dy.  ws_d: bg_conv2d_bwd_filter_workspace_bytes */
+size_t bg_conv2d_bwd_filter_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
+int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                         int ksize, int stride, float beta, float scale, void* ws_d, size_t ws_bytes, void* stream);
+/* dst[t][c][r] = src[t][r][c] */
+int bg_transpose_last2(const float* src, float* dst, int T, int R, int C, void* stream);
+
+/* ---- Dense (demo_celeba.py:55,124): row-major C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) --- */
+int bg_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, int transA, int transB,
+                const float* bias, float beta, float scale, void* stream);
+
+/* ---- reductions: column sums of a row-major [M,N] matrix (bias grads, BN statistics, JVP tail) */
+size_t bg_colsum_workspace_bytes(int M, int N);
+/* out[n] = beta*out[n] + scale * sum_m f(x[m,n]) ; square != 0 sums x^2 */
+int bg_colsum_f32(const float* x, float* out, int M, int N, int square, float beta, float scale,
+                  void* ws_d, size_t ws_bytes, void* stream);
+
+/* ---- BatchNormalization + LeakyReLU (demo_celeba.py:56-90), x viewed as [M, C] --------------- */
+/* training forward: batch mean / biased var -> y = lrelu(gamma*(x-mean)*inv + beta); saves mean, inv;
+ * moving stats <- moving*momentum + stat*(1-momentum), var scaled by M/(M-1) when unbiased != 0. */
+size_t bg_bn_workspace_bytes(int M, int C);
+int bg_bn_train_fwd(const float* x, float* y, int M, int C, const float* gamma, const float* beta,
+                    float* moving_mean, float* moving_var, float* save_mean, float* save_inv,
+                    float eps, float momentum, int unbiased, float lrelu_alpha,
+                    void* ws_d, size_t ws_bytes, void* stream);
+/* inference forward with moving stats (generator inside the D-step, wgan.py:135). */
+int bg_bn_infer_fwd(const float* x, float* y, int M, int C, const float* gamma, const float* beta,
+                    const float* moving_mean, const float* moving_var, float eps, float lrelu_alpha, void* stream);
+/* backward through lrelu + training BN: dy is the gradient w.r.t. y (post-lrelu), y the saved output. */
+int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, int M, int C,
+                    const float* gamma, const float* save_mean, const float* save_inv,
+                    float* dgamma, float* dbeta, float lrelu_alpha, void* ws_d, size_t ws_bytes, void* stream);
+
+/* ---- pointwise ------------------------------------------------------------------------------ */
+/* wgan.py:239: xhat[b,:] = r[b,:] + alpha[b] * (f[b,:] - r[b,:]) */
+int bg_lerp_f32(const float* r, const float* f, const float* alpha_b, float* xhat, int B, int n_per, void* stream);
+/* wgan.py:245: norm[b] = ||g[b,:]||_2 */
+int bg_row_norm_f32(const float* g, float* norm_b, int B, int n_per, void* stream);
+/* second-order seed: out[b,:] = coef * (norm[b]-1)/norm[b] * g[b,:]   (d mean((n-1)^2) / dg) */
+int bg_gp_seed_f32(const float* g, const float* norm_b, float coef, float* out, int B, int n_per, void* stream);
+/* out = d * (ref > 0 ? 1 : alpha) [* keep ? scale : 0] */
+int bg_mul_grad_f32(const float* d, const float* ref, const uint8_t* keep, float alpha, float scale,
+                    float* out, size_t n, void* stream);
+/* out = dy * (1 - y^2) */
+int bg_tanh_bwd_f32(const float* dy, const float* y, float* out, size_t n, void* stream);
+/* out[b, k] = s[b] * w[k] */
+int bg_outer_f32(const float* s_b, const float* w_k, float* out, int B, int K, void* stream);
+int bg_fill_f32(float* x, float v, size_t n, void* stream);
+int bg_scale_f32(float* x, float v, size_t n, void* stream);
+
+/* ---- losses (wgan.py:128-130,155-157,272-285) ----------------------------------------------- */
+/* From scores fs[B], rs[B] and the per-sample norms n[B] of the GP gradient:
+ *   metrics_d[0..5] = mean(fs), mean(rs), disc_loss (mean of the [B] vector), gp_term, mean(norm_term), GP
+ *   dfs[b] = vec_scale*inv_gbs + e_drift*sign(fs[b]);  drs[b] = -vec_scale*inv_gbs + e_drift*sign(rs[b])
+ * vec_scale is B when the reference's [B]-vector loss quirk (Q1) is reproduced, 1 otherwise. */
+int bg_wgangp_d_loss(const float* fs, const float* rs, const float* norm_b, int B, float inv_gbs,
+                     float gp_coef, float e_drift, float vec_scale, float* dfs, float* drs,
+                     float* metrics_d, void* stream);
+/* metrics_d[0] = mean(s), metrics_d[1] = -sum(s)*inv_gbs ; ds[b] = -inv_gbs */
+int bg_wgan_g_loss(const float* s, int B, float inv_gbs, float* ds, float* metrics_d, void* stream);
+
+/* ---- optimiser: tf.keras.optimizers.Adam (wgan.py:56-61,141,167) ----------------------------- */
+/* lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller (host) per step. */
+int bg_adam_f32(float* theta, float* m, float* v, const float* g, size_t n, float lr_t, float b1, float b2,
+                float eps, void* stream);
+
+/* ---- RNG: tf.random.uniform (wgan.py:118,237) and Dropout masks; counter-based, own stream ---- */
+int bg_uniform_f32(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
+int bg_keep_mask_u8(uint8_t* out, size_t n, float keep_prob, uint64_t seed, uint64_t offset, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BGAN_H */

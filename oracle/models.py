@@ -47,7 +47,7 @@ def generator_spec(name):
         return _g_stack(4, 512, [(512, 1, None), (256, 2, None), (128, 2, None), (64, 2, None),
                                  (32, 2, None)], 3)
     if name == "tiny":       # test-only: 8x8x3 images, same layer types
-        return _g_stack(2, 16, [(16, 1, None), (8, 2, None), (8, 2, None)], 3)
+        return _g_stack(2, 32, [(32, 1, None), (16, 2, None), (16, 2, None)], 3)
     if name == "tiny_mnist":  # test-only: ConvT with fused tanh and 1 channel, odd sizes
         return _g_stack(3, 8, [(8, 1, None), (4, 2, None), (1, 2, "tanh")], None)
     raise KeyError(name)
@@ -61,7 +61,7 @@ def discriminator_spec(name):
     if name == "celeba64":
         return _d_stack([32, 64, 128, 256, 512])
     if name == "tiny":
-        return _d_stack([8, 16])
+        return _d_stack([16, 32])
     if name == "tiny_mnist":
         return _d_stack([4, 8])
     raise KeyError(name)

@@ -1,0 +1,95 @@
+"""CPU tests of the boundary: the C-ABI library builds, loads and exports every symbol include/bgan.h declares;
+host-side entry points (blur policy / Gaussian taps) agree with the oracle; argument errors are reported, not
+crashed on.  No device compute is launched here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from oracle import np_ops as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as ge
+    ge._load_build_module().build_lib(verbose=False)
+    from blurred_gan_amd import _lib
+    return _lib.load()
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from blurred_gan_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "bgan.h")).read()
+    declared = set(re.findall(r"\b(bg_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"bg_status", "bg_epi_mode"}
+    assert len(declared) >= 35
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libbgan_hip.so does not export {name}"
+        assert name in _lib.SIGNATURES, f"_lib.py does not bind {name}"
+    assert set(_lib.SIGNATURES) <= declared
+    assert lib.bg_version() == 1
+
+
+def test_host_blur_policy_and_taps_match_oracle(lib):
+    from blurred_gan_amd import ops
+    for std in [0.01, 0.05, 0.2, 0.34, 0.5, 0.99, 1.0, 2.0, 4.94, 5.0, 10.5, 23.5, 42.34, 100.0]:
+        for hw in [(8, 8), (28, 28), (64, 64), (128, 128), (256, 256), (12, 20)]:
+            ks, se, nt = ops.blur_policy(std, *hw)
+            oks, ose, ont = O.blur_policy(std, *hw)
+            assert (ks, nt) == (oks, ont), (std, hw)
+            assert abs(se - ose) <= 1e-6 * max(1.0, ose)
+            g = np.array(ops.gauss_kernel_1d(se, ks), np.float32)
+            ref = O.gaussian_kernel_1d(se, ks, np.float64)
+            assert g.shape == ref.shape
+            np.testing.assert_allclose(g, ref, rtol=3e-6, atol=1e-9)
+            assert abs(float(g.sum()) - 1.0) < 1e-5
+
+
+def test_errors_are_statuses_not_crashes(lib):
+    from blurred_gan_amd import _lib
+    ks, se, nt = C.c_float(), C.c_float(), C.c_int()
+    assert lib.bg_blur_policy(1.0, 0, 8, C.byref(ks), C.byref(se), C.byref(nt)) == -1
+    assert b"bg_blur_policy" in lib.bg_last_error()
+    buf = (C.c_float * 4)()
+    assert lib.bg_gauss_kernel_1d(5.0, 31.0, buf, 4, None) == -5           # capacity too small
+    assert lib.bg_gauss_kernel_1d(5.0, 31.0, None, 4, None) == -6          # null
+    assert lib.bg_conv2d_fwd(None, None, None, 1, 4, 4, 32, 32, 5, 1, None, None) == -6
+    assert lib.bg_gemm_f32(None, None, None, 1, 1, 1, 0, 0, None, 0.0, 1.0, None) == -6
+    with pytest.raises(ValueError):
+        _lib.check(-1, "x")
+    with pytest.raises(_lib.BgError):
+        _lib.check(-4, "x")
+    assert lib.bg_status_string(-3) == b"unsupported configuration"
+    # workspace queries are pure host functions
+    assert lib.bg_blur_workspace_bytes(4, 64, 64, 3, 31) == 0
+    assert lib.bg_blur_workspace_bytes(4, 128, 128, 3, 31) == 4 * 128 * 128 * 3 * 4
+    assert lib.bg_conv2d_bwd_filter_workspace_bytes(256, 32, 32, 32, 64, 5, 2) > 0
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from blurred_gan_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.BgError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "blurred-gan_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src, f"{fn} mentions the oracle"
+    assert "oracle" not in open(os.path.join(ROOT, "blurred_gan_amd.py")).read()
+
+
+def test_cpu_tensors_are_rejected():
+    import torch
+    from blurred_gan_amd import ops
+    x = torch.zeros(1, 4, 4, 3)
+    with pytest.raises(ops.BgDeviceError):
+        ops.blur_nhwc(x, torch.empty_like(x), torch.ones(3), 3)

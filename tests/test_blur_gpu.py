@@ -1,0 +1,75 @@
+"""GPU parity: bg_blur_nhwc_f32 (through the C ABI) vs the float64 oracle."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops as O
+from helpers import dev, POINT_RTOL, POINT_ATOL
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(x, std):
+    from blurred_gan_amd import ops
+    B, H, W, C = x.shape
+    ks, se, nt = ops.blur_policy(std, H, W)
+    taps = torch.tensor(ops.gauss_kernel_1d(se, ks), device="cuda")
+    nb = ops.blur_workspace_bytes(B, H, W, C, nt)
+    tmp = torch.empty(nb // 4 + 4, device="cuda") if nb else None
+    y = ops.blur_nhwc(dev(x), torch.empty(x.shape, device="cuda"), taps, nt, tmp)
+    torch.cuda.synchronize()
+    return y.cpu().numpy(), (ks, se, nt)
+
+
+@pytest.mark.parametrize("shape,std", [
+    ((3, 8, 8, 3), 0.05), ((2, 28, 28, 1), 0.05), ((2, 28, 28, 1), 23.5), ((4, 64, 64, 3), 5.0), ((2, 64, 64, 3), 4.94),
+    ((2, 64, 64, 3), 0.5), ((2, 9, 13, 3), 1.0), ((1, 128, 128, 3), 5.0), ((2, 128, 128, 3), 23.5), ((1, 256, 256, 3), 23.5),
+    ((1, 256, 256, 3), 42.34), ((2, 12, 12, 1), 0.7), ((2, 5, 7, 2), 2.0),
+])
+def test_blur_matches_oracle(shape, std):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=shape).astype(np.float32)
+    y, (ks, se, nt) = _run(x, std)
+    oks, ose, ont = O.blur_policy(std, shape[1], shape[2])
+    assert (ks, nt) == (oks, ont) and abs(se - ose) < 1e-6 * max(1, ose)     # host policy == oracle policy
+    ref = O.blur_images(x.astype(np.float64), std)
+    np.testing.assert_allclose(y, ref, rtol=POINT_RTOL, atol=POINT_ATOL * 4)
+
+
+def test_gauss_kernel_host_matches_oracle():
+    from blurred_gan_amd import ops
+    for std, hw in [(0.05, 28), (1.0, 64), (5.0, 64), (4.94, 64), (23.5, 256), (42.34, 256)]:
+        ks, se, nt = ops.blur_policy(std, hw, hw)
+        g = np.array(ops.gauss_kernel_1d(se, ks), np.float32)
+        ref = O.gaussian_kernel_1d(se, ks, np.float64)
+        assert g.shape == ref.shape
+        np.testing.assert_allclose(g, ref, rtol=2e-6, atol=1e-9)
+
+
+def test_blur_properties_full_size():
+    """Size-independent properties at BASELINE.json's C2 size: self-adjointness, linearity, constant image."""
+    from blurred_gan_amd import ops
+    torch.manual_seed(0)
+    B, H, W, C = 256, 64, 64, 3
+    ks, se, nt = ops.blur_policy(5.0, H, W)
+    taps = torch.tensor(ops.gauss_kernel_1d(se, ks), device="cuda")
+    x = torch.rand(B, H, W, C, device="cuda") * 2 - 1
+    y = torch.rand(B, H, W, C, device="cuda") * 2 - 1
+    bl = lambda t: ops.blur_nhwc(t.contiguous(), torch.empty_like(t), taps, nt)
+    bx, by = bl(x), bl(y)
+    lhs, rhs = (bx.double() * y.double()).sum().item(), (x.double() * by.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs))
+    z = bl(2.0 * x + 3.0 * y)
+    assert (z - (2.0 * bx + 3.0 * by)).abs().max().item() < 2e-5
+    ones = bl(torch.ones(2, H, W, C, device="cuda"))
+    assert abs(ones[0, H // 2, W // 2, 0].item() - 1.0) < 1e-5          # interior preserved
+    g = np.array(ops.gauss_kernel_1d(se, ks), np.float64)
+    assert abs(ones[0, 0, 0, 1].item() - g[nt // 2:].sum() ** 2) < 1e-5  # corner darkened by the truncated sums
+
+
+def test_blur_rejects_bad_arguments():
+    from blurred_gan_amd import ops
+    x = torch.zeros(1, 4, 4, 3, device="cuda")
+    taps = torch.ones(4, device="cuda")
+    with pytest.raises(ValueError):
+        ops.blur_nhwc(x, torch.empty_like(x), taps, 4)          # even tap count

@@ -1,0 +1,149 @@
+"""GPU parity: conv forward / data-gradient / filter-gradient kernels (MFMA, thin and direct paths) vs the
+float64 oracle, plus adjointness at full BASELINE sizes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops as O
+from helpers import dev, conv_tol
+
+pytestmark = pytest.mark.gpu
+
+# (B, H, W, Cin, Cout, stride) -- covers: MFMA BK=32/16, N tails (16), thin-K (Cin 3/1), thin-N (Cout 3/1),
+# direct fallback (8->4), odd spatial sizes, stride 1 and 2, M not a multiple of the tile
+CASES = [
+    (2, 8, 8, 32, 32, 2), (3, 8, 8, 32, 64, 1), (2, 16, 16, 64, 128, 2), (2, 4, 4, 128, 256, 2), (5, 2, 2, 256, 512, 2),
+    (2, 8, 8, 16, 32, 2), (2, 8, 8, 32, 16, 2), (2, 16, 16, 16, 16, 1), (3, 7, 7, 32, 32, 2), (2, 7, 9, 32, 64, 1),
+    (2, 16, 16, 3, 32, 2), (2, 28, 28, 1, 64, 2), (2, 16, 16, 32, 3, 1), (2, 14, 14, 64, 1, 2), (2, 12, 12, 8, 4, 2),
+    (2, 6, 6, 4, 8, 1), (1, 32, 32, 64, 32, 2), (9, 4, 4, 512, 512, 1),
+]
+
+
+def _data(B, H, W, Ci, Co, s, seed=0):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(-1, 1, size=(B, H, W, Ci))
+    w = rng.uniform(-1, 1, size=(5, 5, Ci, Co)) / np.sqrt(25 * Ci)
+    Ho, Wo = -(-H // s), -(-W // s)
+    dy = rng.uniform(-1, 1, size=(B, Ho, Wo, Co))
+    return x, w, dy
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,s", CASES)
+def test_conv_fwd(B, H, W, Ci, Co, s):
+    from blurred_gan_amd import ops
+    x, w, dy = _data(B, H, W, Ci, Co, s)
+    ref = O.conv2d_fwd(x, w, s)
+    wT = dev(np.transpose(w, (0, 1, 3, 2)))
+    y = ops.conv2d_fwd(dev(x), wT, torch.empty(ref.shape, device="cuda"), 5, s)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=conv_tol(25 * Ci, np.abs(ref).max()))
+    # the transposed weight copy made by the library's own transpose kernel
+    wT2 = ops.transpose_last2(dev(w), torch.empty(w.size, device="cuda"), 25, Ci, Co)
+    assert torch.equal(wT2.view(-1), wT.reshape(-1))
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,s", CASES)
+def test_conv_bwd_data(B, H, W, Ci, Co, s):
+    from blurred_gan_amd import ops
+    x, w, dy = _data(B, H, W, Ci, Co, s, seed=1)
+    ref = O.conv2d_bwd_data(dy, w, s, (H, W))
+    dx = ops.conv2d_bwd_data(dev(dy), dev(w), torch.empty(x.shape, device="cuda"), 5, s)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dx.cpu().numpy(), ref, rtol=1e-4, atol=conv_tol(25 * Co, np.abs(ref).max()))
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,s", CASES)
+def test_conv_bwd_filter(B, H, W, Ci, Co, s):
+    from blurred_gan_amd import ops
+    x, w, dy = _data(B, H, W, Ci, Co, s, seed=2)
+    ref = O.conv2d_bwd_filter(x, dy, s, 5)
+    nb = ops.conv2d_bwd_filter_workspace_bytes(B, H, W, Ci, Co, 5, s)
+    ws = torch.empty(nb // 4 + 4, device="cuda") if nb else None
+    dw = torch.full(w.shape, 7.0, device="cuda")              # poisoned: beta = 0 must overwrite
+    ops.conv2d_bwd_filter(dev(x), dev(dy), dw, 5, s, 0.0, 1.0, ws)
+    torch.cuda.synchronize()
+    K = dy.shape[0] * dy.shape[1] * dy.shape[2]
+    np.testing.assert_allclose(dw.cpu().numpy(), ref, rtol=1e-4, atol=conv_tol(K, np.abs(ref).max()))
+    # accumulate form: dw = 0.5*dw + 2*grad
+    ops.conv2d_bwd_filter(dev(x), dev(dy), dw, 5, s, 0.5, 2.0, ws)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(dw.cpu().numpy(), 2.5 * ref, rtol=1e-4, atol=2.5 * conv_tol(K, np.abs(ref).max()))
+
+
+def test_epilogues():
+    from blurred_gan_amd import ops
+    from blurred_gan_amd._lib import EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_NONE
+    B, H, W, Ci, Co, s = 2, 8, 8, 32, 32, 2
+    x, w, dy = _data(B, H, W, Ci, Co, s, seed=3)
+    rng = np.random.default_rng(4)
+    bias = rng.normal(size=Co)
+    keep = (rng.uniform(size=dy.shape) >= 0.3).astype(np.uint8)
+    z = O.conv2d_fwd(x, w, s) + bias
+    wT = dev(np.transpose(w, (0, 1, 3, 2)))
+    out = lambda: torch.empty(z.shape, device="cuda")
+    tol = conv_tol(25 * Ci, np.abs(z).max())
+    y = ops.conv2d_fwd(dev(x), wT, out(), 5, s, ops.epilogue(EPI_BIAS_LRELU, bias=dev(bias), keep=dev(keep, torch.uint8), alpha=0.3, scale=1 / 0.7))
+    np.testing.assert_allclose(y.cpu().numpy(), O.dropout_fwd(O.lrelu_fwd(z), keep, 0.3), rtol=1e-4, atol=2 * tol)
+    y = ops.conv2d_fwd(dev(x), wT, out(), 5, s, ops.epilogue(EPI_BIAS_LRELU, bias=dev(bias), alpha=0.3))
+    np.testing.assert_allclose(y.cpu().numpy(), O.lrelu_fwd(z), rtol=1e-4, atol=tol)
+    y = ops.conv2d_fwd(dev(x), wT, out(), 5, s, ops.epilogue(EPI_TANH, bias=dev(bias)))
+    np.testing.assert_allclose(y.cpu().numpy(), np.tanh(z), rtol=1e-4, atol=tol)
+    y = ops.conv2d_fwd(dev(x), wT, out(), 5, s, ops.epilogue(EPI_NONE, bias=dev(bias)))
+    np.testing.assert_allclose(y.cpu().numpy(), z, rtol=1e-4, atol=tol)
+    ref_act = rng.normal(size=x.shape)
+    keep_x = (rng.uniform(size=x.shape) >= 0.3).astype(np.uint8)
+    dxr = O.conv2d_bwd_data(dy, w, s, (H, W))
+    dx = ops.conv2d_bwd_data(dev(dy), dev(w), torch.empty(x.shape, device="cuda"), 5, s,
+                             ops.epilogue(EPI_MUL_GRAD, ref=dev(ref_act), keep=dev(keep_x, torch.uint8), alpha=0.3, scale=1 / 0.7))
+    exp = dxr * O.lrelu_mask(ref_act) * keep_x / 0.7
+    np.testing.assert_allclose(dx.cpu().numpy(), exp, rtol=1e-4, atol=2 * conv_tol(25 * Co, np.abs(dxr).max()))
+
+
+def test_conv_transpose_roles():
+    """Conv2DTranspose forward = bwd_data with the kernel array as is; its filter gradient swaps x and dy."""
+    from blurred_gan_amd import ops
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, size=(2, 4, 4, 32))
+    w = rng.uniform(-1, 1, size=(5, 5, 16, 32)) / 20           # [k,k,c_out,c_in]
+    ref = O.conv2d_transpose_fwd(x, w, 2)
+    y = ops.conv2d_bwd_data(dev(x), dev(w), torch.empty(ref.shape, device="cuda"), 5, 2)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=conv_tol(800, np.abs(ref).max()))
+    dyt = rng.uniform(-1, 1, size=ref.shape)
+    dwr = O.conv2d_transpose_bwd_filter(x, dyt, 2, 5)
+    nb = ops.conv2d_bwd_filter_workspace_bytes(2, 8, 8, 16, 32, 5, 2)
+    ws = torch.empty(nb // 4 + 4, device="cuda") if nb else None
+    dw = ops.conv2d_bwd_filter(dev(dyt), dev(x), torch.empty(w.shape, device="cuda"), 5, 2, 0.0, 1.0, ws)
+    np.testing.assert_allclose(dw.cpu().numpy(), dwr, rtol=1e-4, atol=conv_tol(32, np.abs(dwr).max()))
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,s", [(256, 32, 32, 32, 64, 2), (256, 64, 64, 3, 32, 2), (256, 4, 4, 256, 512, 2),
+                                           (256, 64, 64, 32, 3, 1), (256, 16, 16, 128, 64, 2)])
+def test_adjointness_full_size(B, H, W, Ci, Co, s):
+    """<conv(x), dy> == <x, conv^T(dy)> == <w, wgrad(x, dy)> at the C2 layer sizes (no oracle needed)."""
+    from blurred_gan_amd import ops
+    torch.manual_seed(0)
+    x = torch.rand(B, H, W, Ci, device="cuda") * 2 - 1
+    w = (torch.rand(5, 5, Ci, Co, device="cuda") * 2 - 1) / (25 * Ci) ** 0.5
+    Ho, Wo = -(-H // s), -(-W // s)
+    dy = torch.rand(B, Ho, Wo, Co, device="cuda") * 2 - 1
+    wT = ops.transpose_last2(w, torch.empty_like(w).view(-1), 25, Ci, Co)
+    y = ops.conv2d_fwd(x, wT, torch.empty(B, Ho, Wo, Co, device="cuda"), 5, s)
+    dx = ops.conv2d_bwd_data(dy, w, torch.empty_like(x), 5, s)
+    nb = ops.conv2d_bwd_filter_workspace_bytes(B, H, W, Ci, Co, 5, s)
+    ws = torch.empty(nb // 4 + 4, device="cuda") if nb else None
+    dw = ops.conv2d_bwd_filter(x, dy, torch.empty_like(w), 5, s, 0.0, 1.0, ws)
+    a = (y.double() * dy.double()).sum().item()
+    b = (x.double() * dx.double()).sum().item()
+    c = (w.double() * dw.double()).sum().item()
+    scale = max(1.0, abs(a))
+    assert abs(a - b) < 2e-4 * scale and abs(a - c) < 2e-4 * scale, (a, b, c)
+
+
+def test_conv_rejects_bad_arguments():
+    from blurred_gan_amd import ops
+    x = torch.zeros(1, 4, 4, 32, device="cuda")
+    w = torch.zeros(9 * 32 * 32, device="cuda")
+    with pytest.raises(ValueError):
+        ops.conv2d_fwd(x, torch.zeros(49 * 32 * 32, device="cuda"), torch.zeros(1, 4, 4, 32, device="cuda"), 7, 1)   # k*k > 25
+    with pytest.raises(ValueError):
+        ops.conv2d_fwd(x, w, torch.zeros(1, 2, 2, 32, device="cuda"), 3, 3)                                          # stride 3

@@ -1,0 +1,108 @@
+"""CPU tests of the reference-shaped host API (no device compute): layer shape inference with the reference's
+own asserts, parameter counts, hyper-parameter dataclasses / CLI / JSON, callbacks' sigma schedule, fit protocol."""
+import argparse
+import json
+
+import numpy as np
+import pytest
+
+import blurred_gan_amd as bg
+from blurred_gan_amd import callbacks, layers, models
+
+
+def test_generator_shapes_follow_reference_asserts():
+    g = models.DCGANGenerator(arch="celeba128")            # constructor runs demo_celeba.py:60-93's asserts
+    assert g.output_shape == (None, 128, 128, 3) and g.input_shape == (None, 100)
+    assert models.DCGANGenerator(arch="mnist").output_shape == (None, 28, 28, 1)
+    assert models.DCGANGenerator(arch="celeba64").output_shape == (None, 64, 64, 3)
+    d = models.DCGANDiscriminator(arch="celeba128")
+    assert d.input_shape == (None, 128, 128, 3) and d.output_shape == (None, 1)
+
+
+@pytest.mark.parametrize("arch,g_n,d_n", [("celeba128", 11738800, 4368048), ("celeba64", 11727200, 4356448), ("mnist", 2280000, 212672)])
+def test_param_counts(arch, g_n, d_n):
+    g, d = models.DCGANGenerator(arch=arch), models.DCGANDiscriminator(arch=arch)
+    kern = lambda m: sum(int(l.vars["kernel"].numel()) for l in m.build()._own_layers() if "kernel" in l.vars)
+    assert kern(g) == g_n and kern(d) == d_n
+    assert g.count_params() > g_n and len(d.trainable_variables) == 2 * (len(models._D[arch]) + 1)
+
+
+def test_blurred_variant_wraps_critic_and_shares_variables():
+    g, d = models.DCGANGenerator(arch="tiny"), models.DCGANDiscriminator(arch="tiny")
+    hp = bg.BlurredWGANGP.HyperParameters(initial_blur_std=1.5)
+    gan = bg.BlurredWGANGP(g, d, hp, bg.TrainingConfig())
+    assert gan.discriminator is not d and gan.discriminator.layers[0] is gan.blur and gan.discriminator.layers[1] is d
+    assert float(gan.std) == 1.5
+    gan.std.assign(0.25)
+    assert float(gan.blur.std) == 0.25
+    # inner model's variables alias the wrapper's store
+    d.trainable_variables[0].fill_(3.0)
+    assert float(gan.discriminator.trainable_variables[0].flatten()[0]) == 3.0
+    assert gan.metrics_names == ["loss", "real_scores", "fake_scores", "gen_loss", "disc_loss", "gp_term", "norm_term", "std"]
+    assert bg.BlurredWGAN.__name__ == "BlurredWGAN" and issubclass(bg.BlurredWGANGP, bg.WGANGP)
+    net = gan.discriminator.net()
+    assert net.blur is gan.blur and [s.kind for s in net.stages] == ["conv", "conv", "dense"]
+    assert all(s.act == "lrelu" and s.drop == 0.3 for s in net.stages[:2])
+
+
+def test_hyperparameter_defaults_cli_and_json(tmp_path):
+    hp = bg.BlurredWGANGP.HyperParameters()
+    assert (hp.learning_rate, hp.d_steps_per_g_step, hp.batch_size, hp.global_batch_size, hp.optimizer) == (0.001, 1, 32, 32, "adam")
+    assert (hp.e_drift, hp.gp_coefficient, hp.initial_blur_std) == (1e-4, 10.0, 0.05)
+    cfg = bg.TrainingConfig()
+    assert (cfg.log_dir, cfg.checkpoint_dir, cfg.save_image_summaries_interval) == ("results/log", "results/log/checkpoints", 50)
+    p = argparse.ArgumentParser()
+    bg.BlurredWGANGP.HyperParameters.add_arguments(p)
+    bg.TrainingConfig.add_arguments(p)
+    a = p.parse_args(["--learning_rate", "0.01", "--global_batch_size", "256", "--log_dir", "x/y"])
+    hp2, cfg2 = bg.BlurredWGANGP.HyperParameters.from_args(a), bg.TrainingConfig.from_args(a)
+    assert hp2.learning_rate == 0.01 and hp2.global_batch_size == 256 and cfg2.log_dir == "x/y"
+    f = tmp_path / "hp.json"
+    hp2.save_json(str(f))
+    assert json.load(open(f))["gp_coefficient"] == 10.0
+    assert bg.BlurredWGANGP.HyperParameters.from_json(str(f)) == hp2
+
+
+def test_blur_decay_controller_schedule_q5():
+    class M:
+        pass
+    m = M()
+    m.n_batches, m.std = 0, bg.gaussian_blur.Variable(0.0)
+    ctl = callbacks.BlurDecayController(total_n_training_examples=600000, max_value=5, min_value=0.01)
+    ctl.set_model(m)
+    for nb, exp in [(0, 5.0), (60000, 5.0 * 0.96), (18750, 5.0 * 0.96 ** 0.3125)]:
+        m.n_batches = nb
+        ctl.on_batch_begin(0, {})
+        assert abs(float(m.std) - exp) < 1e-5
+
+
+def test_execute_every_n_examples_counts():
+    calls = []
+
+    class C(callbacks.ExecuteEveryNExamplesCallback):
+        def function(self, batch, logs):
+            calls.append(self.samples_seen)
+    c = C(n=100)
+    for b in range(10):
+        c.on_batch_end(b, {"size": 32})
+    assert calls == [32, 128, 224, 320]
+
+
+def test_unsupported_layer_patterns_raise():
+    s = layers.Sequential([layers.Dense(4, input_shape=(3,)), layers.LeakyReLU()])
+    with pytest.raises(NotImplementedError):
+        s.net()
+    with pytest.raises(NotImplementedError):
+        layers.Conv2D(4, 3, padding="valid")
+    with pytest.raises(NotImplementedError):
+        bg.WGAN(models.DCGANGenerator(arch="tiny"), models.DCGANDiscriminator(arch="tiny"),
+                bg.WGAN.HyperParameters(optimizer="sgd"), bg.TrainingConfig())
+
+
+def test_gaussian_blur_module_helpers():
+    gb = bg.gaussian_blur
+    assert gb.appropriate_kernel_size(5.0) == 31 and gb.appropriate_std(31) == 5.0
+    assert abs(gb.maximum_reasonable_std(256) - 254 / 6) < 1e-9
+    import torch
+    assert gb.get_data_format(torch.zeros(1, 8, 8, 3)) == "NHWC" and gb.get_data_format(torch.zeros(1, 16, 8, 8)) == "NCHW"
+    assert gb.get_image_dims(torch.zeros(2, 5, 7, 3)) == (5, 7, 3)

@@ -1,0 +1,139 @@
+"""GPU parity: Dense GEMM, column sums, BatchNorm(+LeakyReLU) fwd/bwd, pointwise GP helpers, losses, Adam, RNG."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import np_ops as O
+from helpers import dev
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gemm_variants():
+    from blurred_gan_amd import ops
+    rng = np.random.default_rng(0)
+    for (M, N, K, tA, tB) in [(7, 33, 10, False, False), (10, 33, 7, True, False), (5, 12, 9, False, True), (64, 1, 2048, False, False),
+                              (2048, 1, 16, True, False), (256, 8192, 100, False, False)]:
+        A = rng.normal(size=(K, M) if tA else (M, K))
+        Bm = rng.normal(size=(N, K) if tB else (K, N))
+        bias = rng.normal(size=N)
+        ref = (A.T if tA else A) @ (Bm.T if tB else Bm)
+        C0 = rng.normal(size=(M, N))
+        C = dev(C0)
+        ops.gemm(dev(A), dev(Bm), C, M, N, K, tA, tB, bias=dev(bias), beta=0.5, scale=2.0)
+        np.testing.assert_allclose(C.cpu().numpy(), 2 * ref + bias + 0.5 * C0, rtol=1e-4, atol=1e-4 * math.sqrt(K))
+
+
+def test_colsum():
+    from blurred_gan_amd import ops
+    rng = np.random.default_rng(1)
+    for M, N in [(5, 3), (1000, 32), (4096, 70), (3, 512), (100000, 16)]:
+        x = rng.normal(size=(M, N))
+        ws = torch.empty(ops.colsum_workspace_bytes(M, N) // 4 + 4, device="cuda")
+        out = dev(np.ones(N))
+        ops.colsum(dev(x), out, M, N, ws, beta=2.0, scale=0.5)
+        np.testing.assert_allclose(out.cpu().numpy(), 2.0 + 0.5 * x.sum(0), rtol=1e-4, atol=1e-3)
+        ops.colsum(dev(x), out, M, N, ws, square=True)
+        np.testing.assert_allclose(out.cpu().numpy(), (x * x).sum(0), rtol=1e-4, atol=1e-3)
+
+
+@pytest.mark.parametrize("shape", [(16, 40), (3, 4, 4, 16), (64, 8, 8, 32), (256, 70)])
+def test_batchnorm_lrelu_fwd_bwd(shape):
+    from blurred_gan_amd import ops
+    rng = np.random.default_rng(2)
+    C = shape[-1]
+    M = int(np.prod(shape)) // C
+    x = rng.normal(size=shape) * 2 + 0.5
+    gamma, beta = 1 + 0.3 * rng.normal(size=C), 0.2 * rng.normal(size=C)
+    mm, mv = rng.normal(size=C), 1 + rng.uniform(size=C)
+    u, cache, nm, nv = O.bn_train_fwd(x, gamma, beta, mm, mv)
+    ref = O.lrelu_fwd(u)
+    ws = torch.empty(ops._lib.load().bg_bn_workspace_bytes(M, C) // 4 + 4, device="cuda")
+    y, mmd, mvd = torch.empty(shape, device="cuda"), dev(mm), dev(mv)
+    sm, si = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_train_fwd(dev(x), y, M, C, dev(gamma), dev(beta), mmd, mvd, sm, si, ws, unbiased=(len(shape) == 4))
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(mmd.cpu().numpy(), nm, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(mvd.cpu().numpy(), nv, rtol=1e-4, atol=1e-5)
+    # inference mode
+    yi = ops.bn_infer_fwd(dev(x), torch.empty(shape, device="cuda"), M, C, dev(gamma), dev(beta), dev(mm), dev(mv))
+    np.testing.assert_allclose(yi.cpu().numpy(), O.lrelu_fwd(O.bn_infer_fwd(x, gamma, beta, mm, mv)), rtol=1e-4, atol=2e-5)
+    # backward through lrelu + BN
+    dy = rng.normal(size=shape)
+    dz = dy * O.lrelu_mask(u)
+    dxr, dgr, dbr = O.bn_train_bwd(dz, gamma, cache)
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    dx = ops.bn_train_bwd(dev(dy), y, dev(x), torch.empty(shape, device="cuda"), M, C, dev(gamma), sm, si, dg, db, ws)
+    np.testing.assert_allclose(dg.cpu().numpy(), dgr, rtol=2e-4, atol=2e-4 * math.sqrt(M))
+    np.testing.assert_allclose(db.cpu().numpy(), dbr, rtol=2e-4, atol=2e-4 * math.sqrt(M))
+    np.testing.assert_allclose(dx.cpu().numpy(), dxr, rtol=2e-4, atol=2e-5 * max(1, np.abs(dxr).max()))
+
+
+def test_pointwise_and_losses():
+    from blurred_gan_amd import ops
+    rng = np.random.default_rng(3)
+    B, n = 6, 8 * 8 * 3
+    r, f, a = rng.normal(size=(B, n)), rng.normal(size=(B, n)), rng.uniform(size=B)
+    xh = ops.lerp(dev(r), dev(f), dev(a), torch.empty(B, n, device="cuda"))
+    np.testing.assert_allclose(xh.cpu().numpy(), r + a[:, None] * (f - r), rtol=1e-5, atol=1e-6)
+    nr = ops.row_norm(dev(f), torch.empty(B, device="cuda"))
+    np.testing.assert_allclose(nr.cpu().numpy(), np.linalg.norm(f, axis=1), rtol=1e-5)
+    gs = ops.gp_seed(dev(f), nr, 0.7, torch.empty(B, n, device="cuda"))
+    nn = np.linalg.norm(f, axis=1)
+    np.testing.assert_allclose(gs.cpu().numpy(), 0.7 * ((nn - 1) / nn)[:, None] * f, rtol=1e-4, atol=1e-6)
+    keep = (rng.uniform(size=(B, n)) > 0.3).astype(np.uint8)
+    mg = ops.mul_grad(dev(r), dev(f), torch.empty(B, n, device="cuda"), keep=dev(keep, torch.uint8), alpha=0.3, scale=1 / 0.7)
+    np.testing.assert_allclose(mg.cpu().numpy(), r * O.lrelu_mask(f) * keep / 0.7, rtol=1e-5, atol=1e-6)
+    y = np.tanh(r)
+    tb = ops.tanh_bwd(dev(f), dev(y), torch.empty(B, n, device="cuda"))
+    np.testing.assert_allclose(tb.cpu().numpy(), f * (1 - y * y), rtol=1e-5, atol=1e-6)
+    ot = ops.outer(dev(a), dev(r[0]), torch.empty(B, n, device="cuda"))
+    np.testing.assert_allclose(ot.cpu().numpy(), np.outer(a, r[0]), rtol=1e-6)
+    # D loss: wgan.py:130, 277-285 incl. the [B]-vector quirk scale
+    fs, rs, norms = rng.normal(size=B), rng.normal(size=B), 1 + rng.uniform(size=B)
+    fs[0] = 0.0
+    dfs, drs, met = torch.empty(B, device="cuda"), torch.empty(B, device="cuda"), torch.empty(8, device="cuda")
+    ops.wgangp_d_loss(dev(fs), dev(rs), dev(norms), 1 / 32, 10.0, 1e-4, float(B), dfs, drs, met)
+    gp = ((norms - 1) ** 2).mean()
+    norm_term = 1e-4 * (np.abs(fs) + np.abs(rs))
+    m = met.cpu().numpy()
+    np.testing.assert_allclose(m[:6], [fs.mean(), rs.mean(), (fs - rs).sum() / 32 + 10 * gp + norm_term.mean(), 10 * gp,
+                                       norm_term.mean(), gp], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(dfs.cpu().numpy(), B / 32 + 1e-4 * np.sign(fs), rtol=1e-6)
+    np.testing.assert_allclose(drs.cpu().numpy(), -B / 32 + 1e-4 * np.sign(rs), rtol=1e-6)
+    ds, gm = torch.empty(B, device="cuda"), torch.empty(4, device="cuda")
+    ops.wgan_g_loss(dev(fs), 1 / 32, ds, gm)
+    np.testing.assert_allclose(gm.cpu().numpy()[:2], [fs.mean(), -fs.sum() / 32], rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(ds.cpu().numpy(), -1 / 32)
+
+
+def test_adam_matches_oracle():
+    from blurred_gan_amd import ops
+    rng = np.random.default_rng(4)
+    n = 10007
+    th, m, v = rng.normal(size=n), np.zeros(n), np.zeros(n)
+    thd, md, vd = dev(th), dev(m), dev(v)
+    for t in range(1, 4):
+        g = rng.normal(size=n) * 10.0 ** rng.integers(-6, 1, size=n)
+        th, m, v = O.adam_update(th, m, v, g, t, 1e-3)
+        lr_t = 1e-3 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
+        ops.adam(thd, md, vd, dev(g), lr_t)
+    np.testing.assert_allclose(thd.cpu().numpy(), th, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(md.cpu().numpy(), m, rtol=1e-5, atol=1e-9)
+    np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=1e-5, atol=1e-12)
+
+
+def test_rng_statistics_and_determinism():
+    from blurred_gan_amd import ops
+    n = 1 << 20
+    u = ops.uniform(torch.empty(n, device="cuda"), 123, 0).cpu().numpy()
+    assert u.min() >= 0.0 and u.max() < 1.0
+    assert abs(u.mean() - 0.5) < 2e-3 and abs(u.var() - 1 / 12) < 2e-3
+    u2 = ops.uniform(torch.empty(n, device="cuda"), 123, 0).cpu().numpy()
+    assert np.array_equal(u, u2)                                        # counter-based: same (seed, offset) -> same stream
+    u3 = ops.uniform(torch.empty(n, device="cuda"), 123, n // 4).cpu().numpy()
+    assert not np.array_equal(u, u3) and abs(np.corrcoef(u, u3)[0, 1]) < 5e-3
+    k = ops.keep_mask(torch.empty(n + 3, dtype=torch.uint8, device="cuda"), 0.7, 5, 0).cpu().numpy()
+    assert set(np.unique(k)) <= {0, 1} and abs(k.mean() - 0.7) < 2e-3
