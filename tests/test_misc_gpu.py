@@ -121,8 +121,8 @@ def test_adam_matches_oracle():
         lr_t = 1e-3 * math.sqrt(1 - 0.999 ** t) / (1 - 0.9 ** t)
         ops.adam(thd, md, vd, dev(g), lr_t)
     np.testing.assert_allclose(thd.cpu().numpy(), th, rtol=1e-5, atol=1e-6)
-    np.testing.assert_allclose(md.cpu().numpy(), m, rtol=1e-5, atol=1e-9)
-    np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=1e-5, atol=1e-12)
+    np.testing.assert_allclose(md.cpu().numpy(), m, rtol=1e-5, atol=2e-7)    # fp32 cancellation between steps (|g| up to ~3)
+    np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=3e-5, atol=1e-12)   # (1 - 0.999f) differs from 1e-3 by 1.3e-5 in float32, as in TF
 
 
 def test_rng_statistics_and_determinism():
