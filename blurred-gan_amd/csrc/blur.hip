@@ -13,42 +13,75 @@
 namespace {
 
 constexpr int kBlurThreads = 256;
+constexpr int kFusedThreads = 1024;   // 16 waves per CU: the fused kernel is LDS-latency bound, not bandwidth bound
+constexpr int kR = 4;                 // outputs per thread along the filtered axis (register sliding window)
 
-__global__ __launch_bounds__(kBlurThreads) void blur_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                                  int H, int W, int C,
-                                                                  const float* __restrict__ taps, int T) {
+// Both passes: each thread produces kR consecutive outputs along the filtered axis from one sweep over the
+// T + kR - 1 source samples they share -- 2 LDS reads (sample + tap broadcast) per kR FMAs.
+__global__ __launch_bounds__(kFusedThreads) void blur_fused_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                   int H, int W, int C,
+                                                                   const float* __restrict__ taps, int T) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int WC = W * C, n = H * WC, half = T >> 1;
+  const int npad = (n + 3) & ~3;
   float* s0 = lds;
-  float* s1 = lds + ((n + 3) & ~3);
+  float* s1 = lds + npad;
+  float* tp = lds + 2 * npad;            // taps, followed by kR zeros
   const float* xi = x + (size_t)blockIdx.x * n;
   float* yi = y + (size_t)blockIdx.x * n;
   const int tid = threadIdx.x;
+  for (int j = tid; j < T + kR; j += kFusedThreads) tp[j] = j < T ? taps[j] : 0.f;
   if ((n & 3) == 0) {
-    for (int e = tid * 4; e < n; e += kBlurThreads * 4) *reinterpret_cast<float4*>(s0 + e) = *reinterpret_cast<const float4*>(xi + e);
+    for (int e = tid * 4; e < n; e += kFusedThreads * 4) *reinterpret_cast<float4*>(s0 + e) = *reinterpret_cast<const float4*>(xi + e);
   } else {
-    for (int e = tid; e < n; e += kBlurThreads) s0[e] = xi[e];
+    for (int e = tid; e < n; e += kFusedThreads) s0[e] = xi[e];
   }
   __syncthreads();
-  // pass 1: along H (gaussian_blur.py:116-122)
-  for (int e = tid; e < n; e += kBlurThreads) {
-    const int h = e / WC;
-    const int jlo = max(0, half - h), jhi = min(T, H + half - h);
-    const float* col = s0 + e - half * WC;
-    float acc = 0.f;
-    for (int j = jlo; j < jhi; ++j) acc = fmaf(taps[j], col[j * WC], acc);
-    s1[e] = acc;
+  // pass 1: along H (gaussian_blur.py:116-122); item = (column element e0, group of kR rows)
+  const int HQ = (H + kR - 1) / kR;
+  for (int item = tid; item < WC * HQ; item += kFusedThreads) {
+    const int hq = item / WC, e0 = item - hq * WC;
+    const int h0 = hq * kR;
+    float acc[kR], tw[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) { acc[r] = 0.f; tw[r] = 0.f; }
+    for (int j = 0; j < T + kR - 1; ++j) {
+#pragma unroll
+      for (int r = kR - 1; r > 0; --r) tw[r] = tw[r - 1];
+      tw[0] = tp[j];
+      const int srow = h0 - half + j;
+      const float v = (unsigned)srow < (unsigned)H ? s0[srow * WC + e0] : 0.f;
+#pragma unroll
+      for (int r = 0; r < kR; ++r) acc[r] = fmaf(tw[r], v, acc[r]);   // output h0+r uses tap j-r
+    }
+#pragma unroll
+    for (int r = 0; r < kR; ++r)
+      if (h0 + r < H) s1[(h0 + r) * WC + e0] = acc[r];
   }
   __syncthreads();
-  // pass 2: along W (gaussian_blur.py:124-130)
-  for (int e = tid; e < n; e += kBlurThreads) {
-    const int h = e / WC;
-    const int w = (e - h * WC) / C;
-    const int jlo = max(0, half - w), jhi = min(T, W + half - w);
-    const float* row = s1 + e - half * C;
-    float acc = 0.f;
-    for (int j = jlo; j < jhi; ++j) acc = fmaf(taps[j], row[j * C], acc);
-    yi[e] = acc;
+  // pass 2: along W (gaussian_blur.py:124-130); item = (row h, group of kR columns, channel c)
+  const int WQ = (W + kR - 1) / kR;
+  for (int item = tid; item < H * WQ * C; item += kFusedThreads) {
+    const int c = item % C;
+    const int t2 = item / C;
+    const int wq = t2 % WQ, h = t2 / WQ;
+    const int w0 = wq * kR;
+    const float* row = s1 + h * WC + c;
+    float acc[kR], tw[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) { acc[r] = 0.f; tw[r] = 0.f; }
+    for (int j = 0; j < T + kR - 1; ++j) {
+#pragma unroll
+      for (int r = kR - 1; r > 0; --r) tw[r] = tw[r - 1];
+      tw[0] = tp[j];
+      const int scol = w0 - half + j;
+      const float v = (unsigned)scol < (unsigned)W ? row[scol * C] : 0.f;
+#pragma unroll
+      for (int r = 0; r < kR; ++r) acc[r] = fmaf(tw[r], v, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < kR; ++r)
+      if (w0 + r < W) yi[(h * W + w0 + r) * C + c] = acc[r];
   }
 }
 
@@ -73,7 +106,7 @@ __global__ __launch_bounds__(kBlurThreads) void blur_pass_kernel(const float* __
   }
 }
 
-size_t fused_lds_bytes(int H, int W, int C) { return 2 * (size_t)(((H * W * C) + 3) & ~3) * sizeof(float); }
+size_t fused_lds_bytes(int H, int W, int C) { return (2 * (size_t)(((H * W * C) + 3) & ~3) + 512) * sizeof(float); }
 constexpr size_t kFusedLdsCap = 150 * 1024;
 
 }  // namespace
@@ -117,7 +150,7 @@ int bg_gauss_kernel_1d(float sigma_eff, float kernel_size, float* taps_host, int
 size_t bg_blur_workspace_bytes(int B, int H, int W, int C, int n_taps) {
   (void)n_taps;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-  if (fused_lds_bytes(H, W, C) <= kFusedLdsCap) return 0;
+  if (fused_lds_bytes(H, W, C) <= kFusedLdsCap && n_taps <= 500) return 0;
   return (size_t)B * H * W * C * sizeof(float);
 }
 
@@ -131,7 +164,7 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   const double flops = 4.0 * n_taps * (double)total, bytes = 8.0 * (double)total;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const size_t lds = fused_lds_bytes(H, W, C);
-  if (lds <= kFusedLdsCap) {
+  if (lds <= kFusedLdsCap && n_taps <= 500) {
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_fused_kernel),
@@ -140,7 +173,7 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
       attr_set = true;
     }
     bg::Launch L(stream, "blur_fused", flops, bytes);
-    hipLaunchKernelGGL(blur_fused_kernel, dim3(B), dim3(kBlurThreads), lds, s, x, y, H, W, C, taps_d, n_taps);
+    hipLaunchKernelGGL(blur_fused_kernel, dim3(B), dim3(kFusedThreads), lds, s, x, y, H, W, C, taps_d, n_taps);
     return L.done("blur_fused_kernel");
   }
   BG_REQUIRE(tmp_d != nullptr, BG_ERR_WORKSPACE, "bg_blur_nhwc_f32: image of %zu bytes needs tmp_d (see bg_blur_workspace_bytes)",

@@ -168,8 +168,78 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GatherParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// thin-N: one thread per output pixel, all N <= 4 channels; Ck % 4 == 0
+// thin-N (N <= 4 output channels): one thread per output pixel of an 8 x 32 anchor tile.  The input patch
+// (tile + tap halo, CK channels) is staged once through LDS with coalesced float4 loads and re-used by
+// every tap; weights come through the scalar cache (wave-uniform addresses).  Pixel stride in LDS is
+// CK+4 floats so the per-lane ds_read_b128 of neighbouring pixels is bank-conflict free.
 // ------------------------------------------------------------------------------------------------
+constexpr int kThinTH = 8, kThinTW = 32;
+
+template <int CK>
+__global__ __launch_bounds__(256) void conv_thin_n_patch_kernel(const GatherParams p, int tiles_x, int tiles_y) {
+  extern __shared__ __attribute__((aligned(16))) float patch[];
+  constexpr int CS = CK + 4, Q = CK / 4;
+  const int phase = blockIdx.z % p.nphase, b = blockIdx.z / p.nphase;
+  const GatherPhase& g = p.ph[phase];
+  const int a0 = blockIdx.y * kThinTH, x0 = blockIdx.x * kThinTW;
+  if (a0 >= g.Ha || x0 >= g.Wa) return;
+  // halo of this phase's tap set
+  int dmin_y = 127, dmax_y = -127, dmin_x = 127, dmax_x = -127;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int dy = bg::tap_dy(g.tap[t]), dx = bg::tap_dx(g.tap[t]);
+    dmin_y = min(dmin_y, dy); dmax_y = max(dmax_y, dy);
+    dmin_x = min(dmin_x, dx); dmax_x = max(dmax_x, dx);
+  }
+  const int PH = (kThinTH - 1) * p.ss + (dmax_y - dmin_y) + 1;
+  const int PW = (kThinTW - 1) * p.ss + (dmax_x - dmin_x) + 1;
+  const int sy0 = a0 * p.ss + dmin_y, sx0 = x0 * p.ss + dmin_x;
+  const float* src = p.A + (size_t)b * p.Hs * p.Ws * CK;
+  for (int idx = threadIdx.x; idx < PH * PW * Q; idx += 256) {
+    const int q = idx % Q, pix = idx / Q;
+    const int py = pix / PW, px = pix - py * PW;
+    const int sy = sy0 + py, sx = sx0 + px;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
+      v = *reinterpret_cast<const float4*>(src + ((size_t)sy * p.Ws + sx) * CK + q * 4);
+    *reinterpret_cast<float4*>(patch + pix * CS + q * 4) = v;
+  }
+  __syncthreads();
+  const int ty = threadIdx.x / kThinTW, tx = threadIdx.x % kThinTW;
+  const int N = p.N;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const float* base = patch + ((ty * p.ss - dmin_y) * PW + tx * p.ss - dmin_x) * CS;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int tp = g.tap[t];
+    const float* a = base + (bg::tap_dy(tp) * PW + bg::tap_dx(tp)) * CS;
+    const float* w = p.Wt + (size_t)bg::tap_wi(tp) * N * CK;     // wave-uniform -> scalar loads
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      const float4 av = *reinterpret_cast<const float4*>(a + q * 4);
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        if (n < N) {
+          const float4 wv = *reinterpret_cast<const float4*>(w + n * CK + q * 4);
+          acc[n] = fmaf(av.x, wv.x, acc[n]);
+          acc[n] = fmaf(av.y, wv.y, acc[n]);
+          acc[n] = fmaf(av.z, wv.z, acc[n]);
+          acc[n] = fmaf(av.w, wv.w, acc[n]);
+        }
+      }
+    }
+  }
+  const int a_ = a0 + ty, bx = x0 + tx;
+  if (a_ < g.Ha && bx < g.Wa) {
+    const size_t dst = ((size_t)b * p.Hd + a_ * p.ds + g.py) * p.Wd + bx * p.ds + g.px;
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+      if (n < N) {
+        const size_t idx = dst * N + n;
+        p.C[idx] = bg::apply_epilogue(p, acc[n], idx, n);
+      }
+  }
+}
+
+// generic thin-N fallback (any CK % 4 == 0): one thread per output pixel, operands straight from L1/L2
 __global__ __launch_bounds__(256) void conv_thin_n_kernel(const GatherParams p) {
   const GatherPhase& g = p.ph[blockIdx.z];
   const int Mph = p.B * g.Ha * g.Wa;
@@ -206,6 +276,103 @@ __global__ __launch_bounds__(256) void conv_thin_n_kernel(const GatherParams p) 
       const size_t idx = (size_t)dst * N + n;
       p.C[idx] = bg::apply_epilogue(p, acc[n], idx, n);
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// thin-K on MFMA (Ck <= 4 input channels: critic's first conv, data-grad of the RGB conv, MNIST 1->64).
+// The tap is folded into the contraction index, kf = tap*Ck + c (<= 100), so one 8 x 16 anchor tile is
+// C[128 px, N] = A[128, KF] * W[KF, N] with A read straight out of the LDS-resident input patch:
+// lane address = pixel base + koff[kf] (per-k offset table in LDS).  Weights for the whole N tile sit in LDS.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTkTH = 8, kTkTW = 16, kTkMaxKF = 104;
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_thin_k_mfma_kernel(const GatherParams p) {
+  extern __shared__ __attribute__((aligned(16))) float tk_lds[];
+  constexpr int NP = 32 * NT;
+  __shared__ int koff[kTkMaxKF];
+  const int phase = blockIdx.z % p.nphase, b = blockIdx.z / p.nphase;
+  const GatherPhase& g = p.ph[phase];
+  const int a0 = blockIdx.y * kTkTH, x0 = blockIdx.x * kTkTW;
+  if (a0 >= g.Ha || x0 >= g.Wa) return;
+  const int n0 = 0;   // grid covers one N tile (N <= 32*NT), see dispatch
+  const int Ck = p.Ck;
+  int dmin_y = 127, dmax_y = -127, dmin_x = 127, dmax_x = -127;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int dy = bg::tap_dy(g.tap[t]), dx = bg::tap_dx(g.tap[t]);
+    dmin_y = min(dmin_y, dy); dmax_y = max(dmax_y, dy);
+    dmin_x = min(dmin_x, dx); dmax_x = max(dmax_x, dx);
+  }
+  const int PH = (kTkTH - 1) * p.ss + (dmax_y - dmin_y) + 1;
+  const int PW = (kTkTW - 1) * p.ss + (dmax_x - dmin_x) + 1;
+  const int KF = g.ntaps * Ck, KFP = (KF + 1) & ~1;
+  float* Bs = tk_lds;                       // [KFP][NP]
+  float* patch = tk_lds + kTkMaxKF * NP;    // [PH*PW][Ck]
+  const int tid = threadIdx.x;
+  // weights: Bs[kf][n] = Wt[wi(t)][n][c]
+  for (int idx = tid; idx < KFP * NP; idx += 256) {
+    const int kf = idx / NP, n = idx - kf * NP;
+    float v = 0.f;
+    if (kf < KF && n0 + n < p.N) {
+      const int t = kf / Ck, c = kf - t * Ck;
+      v = p.Wt[((size_t)bg::tap_wi(g.tap[t]) * p.N + n0 + n) * Ck + c];
+    }
+    Bs[idx] = v;
+  }
+  if (tid < KFP) {
+    int o = 0;
+    if (tid < KF) {
+      const int t = tid / Ck, c = tid - t * Ck;
+      o = ((bg::tap_dy(g.tap[t]) - dmin_y) * PW + bg::tap_dx(g.tap[t]) - dmin_x) * Ck + c;
+    }
+    koff[tid] = o;
+  }
+  const int sy0 = a0 * p.ss + dmin_y, sx0 = x0 * p.ss + dmin_x;
+  const float* src = p.A + (size_t)b * p.Hs * p.Ws * Ck;
+  const int rowlen = PW * Ck;
+  for (int idx = tid; idx < PH * rowlen; idx += 256) {
+    const int py = idx / rowlen, rem = idx - py * rowlen;
+    const int px = rem / Ck;
+    const int sy = sy0 + py, sx = sx0 + px;
+    float v = 0.f;
+    if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws) v = src[((size_t)sy * p.Ws + sx0) * Ck + rem];
+    patch[idx] = v;
+  }
+  __syncthreads();
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int ty = 2 * wave + (i >> 4), tx = i & 15;
+  const float* abase = patch + (ty * p.ss * PW + tx * p.ss) * Ck;
+  const float* bbase = Bs + i;
+  floatx16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+#pragma unroll 2
+  for (int kk = 0; kk < KFP; kk += 2) {
+    const int k = kk + half;
+    const float a = abase[koff[k]];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bbase[k * NP + j * 32], acc[j], 0, 0, 0);
+  }
+  // epilogue: reg r of lane l -> pixel row (r&3) + 8*(r>>2) + 4*(l>>5) of this wave's 32, column l&31
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int pi = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int a_ = a0 + 2 * wave + (pi >> 4), bx = x0 + (pi & 15);
+    if (a_ < g.Ha && bx < g.Wa) {
+      const size_t dst = ((size_t)b * p.Hd + a_ * p.ds + g.py) * p.Wd + bx * p.ds + g.px;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = n0 + j * 32 + i;
+        if (n < p.N) {
+          const size_t idx = dst * p.N + n;
+          p.C[idx] = bg::apply_epilogue(p, acc[j][r], idx, n);
+        }
+      }
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,11 +506,68 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     snprintf(name, sizeof name, "conv_igemm_%s", tag);
     return (p.Ck % 32 == 0) ? dispatch_igemm<32>(p, stream, name) : dispatch_igemm<16>(p, stream, name);
   }
+  if (p.N <= 4 && (p.Ck == 16 || p.Ck == 32 || p.Ck == 64)) {
+    // LDS patch kernel: patch = anchor tile + tap halo of the widest phase
+    size_t lds = 0;
+    int tiles_x = 0, tiles_y = 0;
+    for (int i = 0; i < p.nphase; ++i) {
+      int mny = 127, mxy = -127, mnx = 127, mxx = -127;
+      for (int t = 0; t < p.ph[i].ntaps; ++t) {
+        const int dy = bg::tap_dy(p.ph[i].tap[t]), dx = bg::tap_dx(p.ph[i].tap[t]);
+        mny = std::min(mny, dy); mxy = std::max(mxy, dy); mnx = std::min(mnx, dx); mxx = std::max(mxx, dx);
+      }
+      const size_t PH = (kThinTH - 1) * p.ss + (mxy - mny) + 1, PW = (kThinTW - 1) * p.ss + (mxx - mnx) + 1;
+      lds = std::max(lds, PH * PW * (size_t)(p.Ck + 4) * sizeof(float));
+      tiles_x = std::max(tiles_x, (int)bg::cdiv(p.ph[i].Wa, kThinTW));
+      tiles_y = std::max(tiles_y, (int)bg::cdiv(p.ph[i].Ha, kThinTH));
+    }
+    if (lds <= 150 * 1024 && (size_t)p.B * p.nphase <= 65535) {
+      static bool attr_set = false;
+      if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_n_patch_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_n_patch_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_n_patch_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+      }
+      snprintf(name, sizeof name, "conv_thin_n_patch_%s", tag);
+      dim3 grid(tiles_x, tiles_y, p.B * p.nphase);
+      bg::Launch L(stream, name, gather_flops(p), 0);
+      if (p.Ck == 16) hipLaunchKernelGGL(conv_thin_n_patch_kernel<16>, grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);
+      else if (p.Ck == 32) hipLaunchKernelGGL(conv_thin_n_patch_kernel<32>, grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);
+      else hipLaunchKernelGGL(conv_thin_n_patch_kernel<64>, grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);
+      return L.done(name);
+    }
+  }
   if (p.N <= 4 && p.Ck % 4 == 0) {
     snprintf(name, sizeof name, "conv_thin_n_%s", tag);
     bg::Launch L(stream, name, gather_flops(p), 0);
     hipLaunchKernelGGL(conv_thin_n_kernel, dim3(bg::cdiv(Mmax, 256), 1, p.nphase), dim3(256), 0, L.s, p);
     return L.done(name);
+  }
+  if (p.Ck <= 4 && p.N <= 64 && (size_t)p.B * p.nphase <= 65535) {
+    const int NT = p.N <= 32 ? 1 : 2;
+    size_t lds = 0;
+    int tiles_x = 0, tiles_y = 0, kfmax = 0;
+    for (int i = 0; i < p.nphase; ++i) {
+      int mny = 127, mxy = -127, mnx = 127, mxx = -127;
+      for (int t = 0; t < p.ph[i].ntaps; ++t) {
+        const int dy = bg::tap_dy(p.ph[i].tap[t]), dx = bg::tap_dx(p.ph[i].tap[t]);
+        mny = std::min(mny, dy); mxy = std::max(mxy, dy); mnx = std::min(mnx, dx); mxx = std::max(mxx, dx);
+      }
+      const size_t PH = (kTkTH - 1) * p.ss + (mxy - mny) + 1, PW = (kTkTW - 1) * p.ss + (mxx - mnx) + 1;
+      lds = std::max(lds, ((size_t)kTkMaxKF * 32 * NT + PH * PW * p.Ck) * sizeof(float));
+      tiles_x = std::max(tiles_x, (int)bg::cdiv(p.ph[i].Wa, kTkTW));
+      tiles_y = std::max(tiles_y, (int)bg::cdiv(p.ph[i].Ha, kTkTH));
+      kfmax = std::max(kfmax, p.ph[i].ntaps * p.Ck);
+    }
+    if (kfmax + 1 <= kTkMaxKF && lds <= 60 * 1024) {
+      snprintf(name, sizeof name, "conv_thin_k_mfma_%s", tag);
+      dim3 grid(tiles_x, tiles_y, p.B * p.nphase);
+      bg::Launch L(stream, name, gather_flops(p), 0);
+      if (NT == 1) hipLaunchKernelGGL(conv_thin_k_mfma_kernel<1>, grid, dim3(256), lds, L.s, p);
+      else hipLaunchKernelGGL(conv_thin_k_mfma_kernel<2>, grid, dim3(256), lds, L.s, p);
+      return L.done(name);
+    }
   }
   if (p.Ck <= 4) {
     snprintf(name, sizeof name, "conv_thin_k_%s", tag);

@@ -27,14 +27,25 @@ struct WgradParams {
   float beta, scale; // applied only when ksplit == 1
 };
 
-template <int BM, int BN, int BKP, int WAVES_M, int WAVES_N, int WAVES_K>
+// MODE 0: grid.y = tap; A = x rows shifted by the tap (float4 over ci), B = dy rows.
+// MODE 1: thin Ci (<= 4): the tap is folded into the M index, i = tap*Ci + ci (im2col columns gathered with
+//         scalar loads); B = dy rows.  One launch covers all taps.
+// MODE 2: thin Co (<= 4), stride 1: contraction runs over INPUT pixels, A = x rows as they lie in memory,
+//         the tap is folded into the N index, j = tap*Co + co, B[k][j] = dy[pixel - tap offset][co].
+template <int BM, int BN, int BKP, int WAVES_M, int WAVES_N, int WAVES_K, int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   static_assert(WAVES_M * WAVES_N * WAVES_K == 4, "4 waves");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / 32, NI = WTN / 32;
-  static_assert(MI >= 1 && NI >= 1, "wave tile");
-  constexpr int TPR_A = BM / 4, RPP_A = 256 / TPR_A, AP = (BKP + RPP_A - 1) / RPP_A;
-  constexpr int TPR_B = BN / 4, RPP_B = 256 / TPR_B, BP = (BKP + RPP_B - 1) / RPP_B;
+  static_assert(MI >= 1 && NI >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  constexpr bool A_IM2COL = MODE == 1, B_IM2COL = MODE == 2;
+  // float4 row loaders
+  constexpr int TPR_A = BM / 4, RPP_A = 256 / TPR_A, AP = A_IM2COL ? 1 : (BKP + RPP_A - 1) / RPP_A;
+  constexpr int TPR_B = BN / 4, RPP_B = 256 / TPR_B, BP = B_IM2COL ? 1 : (BKP + RPP_B - 1) / RPP_B;
+  // scalar im2col loader: thread = (column, row group)
+  constexpr int GW = A_IM2COL ? BM : BN;            // gathered width (padded tap*channel count)
+  constexpr int NRG = 256 / GW;                     // row groups
+  constexpr int GP = (A_IM2COL || B_IM2COL) ? (BKP + NRG - 1) / NRG : 1;
   constexpr int STAGE = BKP * (BM + BN);
   constexpr int RED = (WAVES_K > 1) ? (WAVES_K - 1) * WAVES_M * WAVES_N * MI * NI * 1024 : 0;
   constexpr int SMEM = (2 * STAGE > RED) ? 2 * STAGE : RED;
@@ -54,47 +65,106 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
   const int arow = tid / TPR_A, aq = tid % TPR_A;
   const int brow = tid / TPR_B, bq = tid % TPR_B;
   const int HoWo = p.Ho * p.Wo;
+  // im2col column owned by this thread
+  const int gcol = tid % GW, grg = tid / GW;
+  const int Cthin = A_IM2COL ? p.Ci : p.Co;
+  const bool gvalid = (A_IM2COL || B_IM2COL) && grg < NRG && gcol < p.k * p.k * Cthin;
+  const int gtap = gcol / max(Cthin, 1), gc = gcol - gtap * max(Cthin, 1);
+  const int gkh = gtap / p.k, gkw = gtap - gkh * p.k;
+  // pixel grid the contraction index runs over, and the gathered source tensor
+  const int Hk = B_IM2COL ? p.H : p.Ho, Wk = B_IM2COL ? p.W : p.Wo;
+  const int Hsrc = A_IM2COL ? p.H : p.Ho, Wsrc = A_IM2COL ? p.W : p.Wo;
+  const float* gsrc = A_IM2COL ? p.X : p.DY;
+
   float4 regA[AP], regB[BP];
+  float regG[GP];
+
+  auto gather = [&](int mb) {
+    // rows grg, grg+NRG, ...: decode the first, then step incrementally
+    int m = mb + grg;
+    int b = m / (Hk * Wk);
+    int rem = m - b * (Hk * Wk);
+    int py = rem / Wk, px = rem - py * Wk;
+#pragma unroll
+    for (int i = 0; i < GP; ++i) {
+      float v = 0.f;
+      const int r = grg + i * NRG;
+      if (gvalid && r < BKP && m < m_end) {
+        int sy, sx;
+        if (A_IM2COL) { sy = py * p.s + gkh - p.pt; sx = px * p.s + gkw - p.pl; }
+        else { sy = py - gkh + p.pt; sx = px - gkw + p.pl; }
+        if ((unsigned)sy < (unsigned)Hsrc && (unsigned)sx < (unsigned)Wsrc)
+          v = gsrc[((size_t)(b * Hsrc + sy) * Wsrc + sx) * Cthin + gc];
+      }
+      regG[i] = v;
+      m += NRG;
+      px += NRG;
+      while (px >= Wk) { px -= Wk; if (++py == Hk) { py = 0; ++b; } }
+    }
+  };
 
   auto gload = [&](int step) {
     const int mb = m_begin + step * BKP;
+    if (A_IM2COL || B_IM2COL) gather(mb);
+    if (!A_IM2COL) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int r = arow + i * RPP_A;
-      const int m = mb + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < BKP && m < m_end && ci0 + aq * 4 < p.Ci) {
-        const int b = m / HoWo;
-        const int rem = m - b * HoWo;
-        const int oh = rem / p.Wo;
-        const int ow = rem - oh * p.Wo;
-        const int iy = oh * p.s + kh - p.pt, ix = ow * p.s + kw - p.pl;
-        if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
-          v = *reinterpret_cast<const float4*>(p.X + ((size_t)(b * p.H + iy) * p.W + ix) * p.Ci + ci0 + aq * 4);
+      for (int i = 0; i < AP; ++i) {
+        const int r = arow + i * RPP_A;
+        const int m = mb + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < BKP && m < m_end && ci0 + aq * 4 < p.Ci) {
+          if (MODE == 2) {
+            v = *reinterpret_cast<const float4*>(p.X + (size_t)m * p.Ci + ci0 + aq * 4);
+          } else {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int oh = rem / p.Wo;
+            const int ow = rem - oh * p.Wo;
+            const int iy = oh * p.s + kh - p.pt, ix = ow * p.s + kw - p.pl;
+            if ((unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W)
+              v = *reinterpret_cast<const float4*>(p.X + ((size_t)(b * p.H + iy) * p.W + ix) * p.Ci + ci0 + aq * 4);
+          }
+        }
+        regA[i] = v;
       }
-      regA[i] = v;
     }
+    if (!B_IM2COL) {
 #pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      const int r = brow + i * RPP_B;
-      const int m = mb + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < BKP && m < m_end && co0 + bq * 4 < p.Co) v = *reinterpret_cast<const float4*>(p.DY + (size_t)m * p.Co + co0 + bq * 4);
-      regB[i] = v;
+      for (int i = 0; i < BP; ++i) {
+        const int r = brow + i * RPP_B;
+        const int m = mb + r;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < BKP && m < m_end && co0 + bq * 4 < p.Co) v = *reinterpret_cast<const float4*>(p.DY + (size_t)m * p.Co + co0 + bq * 4);
+        regB[i] = v;
+      }
     }
   };
   auto lstore = [&](int buf) {
     float* sa = smem + buf * STAGE;
     float* sb = sa + BKP * BM;
+    if (A_IM2COL || B_IM2COL) {
+      float* sg = A_IM2COL ? sa : sb;
+      if (grg < NRG) {
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int r = arow + i * RPP_A;
-      if (r < BKP) *reinterpret_cast<float4*>(sa + r * BM + aq * 4) = regA[i];
+        for (int i = 0; i < GP; ++i) {
+          const int r = grg + i * NRG;
+          if (r < BKP) sg[r * GW + gcol] = regG[i];
+        }
+      }
     }
+    if (!A_IM2COL) {
 #pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      const int r = brow + i * RPP_B;
-      if (r < BKP) *reinterpret_cast<float4*>(sb + r * BN + bq * 4) = regB[i];
+      for (int i = 0; i < AP; ++i) {
+        const int r = arow + i * RPP_A;
+        if (r < BKP) *reinterpret_cast<float4*>(sa + r * BM + aq * 4) = regA[i];
+      }
+    }
+    if (!B_IM2COL) {
+#pragma unroll
+      for (int i = 0; i < BP; ++i) {
+        const int r = brow + i * RPP_B;
+        if (r < BKP) *reinterpret_cast<float4*>(sb + r * BN + bq * 4) = regB[i];
+      }
     }
   };
 
@@ -159,19 +229,36 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
   }
 
-  // ---- store: acc reg r of lane l holds C[row(ci) = (r&3) + 8*(r>>2) + 4*(l>>5)][col(co) = l&31]
-  float* out = p.out + (size_t)blockIdx.z * p.k * p.k * p.Ci * p.Co + (size_t)tap * p.Ci * p.Co;
+  // ---- store: acc reg r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+  const int kk = p.k * p.k;
+  float* out = p.out + (size_t)blockIdx.z * kk * p.Ci * p.Co;
   const bool direct = p.ksplit == 1;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NI; ++j) {
-      const int co = co0 + wn * WTN + j * 32 + (lane & 31);
+      const int col = wn * WTN + j * 32 + (lane & 31);
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
-        const int ci = ci0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-        if (ci < p.Ci && co < p.Co) {
-          float* q = out + (size_t)ci * p.Co + co;
+        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        size_t idx;
+        bool ok;
+        if (MODE == 0) {
+          const int ci = ci0 + row, co = co0 + col;
+          ok = ci < p.Ci && co < p.Co;
+          idx = ((size_t)tap * p.Ci + ci) * p.Co + co;
+        } else if (MODE == 1) {
+          const int co = co0 + col;
+          ok = row < kk * p.Ci && co < p.Co;                 // row = tap*Ci + ci
+          idx = (size_t)row * p.Co + co;
+        } else {
+          const int ci = ci0 + row;
+          const int t = col / p.Co, co = col - t * p.Co;     // col = tap*Co + co
+          ok = ci < p.Ci && col < kk * p.Co;
+          idx = ((size_t)t * p.Ci + ci) * p.Co + co;
+        }
+        if (ok) {
+          float* q = out + idx;
           const float v = acc[i][j][r];
           if (direct) *q = (p.beta != 0.f ? p.beta * *q : 0.f) + p.scale * v;
           else *q = v;
@@ -211,6 +298,23 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const WgradParams p) 
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int n,
                                                            int ksplit, float beta, float scale) {
+  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;     // n is a multiple of 4 on this path, slabs 16-B aligned
+  if (e >= n) return;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int z = 0; z < ksplit; ++z) {
+    const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + e);
+    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  }
+  float4 o = make_float4(scale * s.x, scale * s.y, scale * s.z, scale * s.w);
+  if (beta != 0.f) {
+    const float4 d = *reinterpret_cast<const float4*>(dw + e);
+    o.x += beta * d.x; o.y += beta * d.y; o.z += beta * d.z; o.w += beta * d.w;
+  }
+  *reinterpret_cast<float4*>(dw + e) = o;
+}
+
+__global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int n,
+                                                                  int ksplit, float beta, float scale) {
   const int e = blockIdx.x * 256 + threadIdx.x;
   if (e >= n) return;
   float s = 0.f;
@@ -220,7 +324,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 
 struct WgradPlan {
   int mode;     // 0 direct, 1..: mfma config id
-  int ksplit, chunk, tiles_m, tiles_n, bkp;
+  int ksplit, chunk, tiles_m, tiles_n, bkp, taps_in_grid;
 };
 
 WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
@@ -230,8 +334,11 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
   bg::same_pads(W, k, s, &Wo, &pp);
   const long M = (long)B * Ho * Wo;
   const bool mfma = (Ci % 4 == 0) && (Co % 4 == 0) && Ci >= 16 && Co >= 16;
+  const int kk = k * k;
+  const bool thin_ci = Ci <= 4 && Co % 4 == 0 && Co >= 16 && kk * Ci <= 128;
+  const bool thin_co = Co <= 4 && Ci % 4 == 0 && Ci >= 16 && s == 1 && kk * Co <= 128;
   int bm = 0, bn = 0;
-  if (!mfma) {
+  if (!mfma && !thin_ci && !thin_co) {
     pl.mode = 0;
     const long nblk = bg::cdiv((size_t)k * k * Ci * Co, 256);
     long want = std::max(1L, 2048 / nblk);
@@ -240,6 +347,25 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
     pl.ksplit = (int)((M + chunk - 1) / chunk);
     return pl;
   }
+  if (thin_ci) {
+    const int gw = kk * Ci <= 32 ? 32 : (kk * Ci <= 96 ? 96 : 128);
+    pl.bkp = 64;
+    if (gw == 32) { pl.mode = 10; bm = 32; bn = 64; }         // e.g. MNIST 1 -> 64
+    else if (gw == 96) { pl.mode = 11; bm = 96; bn = 32; }    // RGB -> 16/32
+    else { pl.mode = 12; bm = 128; bn = 32; }
+    pl.tiles_m = 1;
+    pl.tiles_n = bg::cdiv(Co, bn);
+    pl.taps_in_grid = 0;
+  } else if (thin_co) {
+    const int gw = kk * Co <= 32 ? 32 : (kk * Co <= 96 ? 96 : 128);
+    pl.bkp = 64;
+    if (gw == 32) { pl.mode = 20; bm = 64; bn = 32; }
+    else if (gw == 96) { pl.mode = 21; bm = 32; bn = 96; }    // 16/32 -> RGB
+    else { pl.mode = 22; bm = 32; bn = 128; }
+    pl.tiles_m = bg::cdiv(Ci, bm);
+    pl.tiles_n = 1;
+    pl.taps_in_grid = 0;
+  } else {
   if (Ci > 64 && Co > 64) { pl.mode = 1; bm = 128; bn = 128; pl.bkp = 32; }
   else if (Ci > 32 && Co > 32) { pl.mode = 2; bm = 64; bn = 64; pl.bkp = 32; }
   else if (Ci > 32) { pl.mode = 3; bm = 64; bn = 32; pl.bkp = 64; }
@@ -247,10 +373,13 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
   else { pl.mode = 5; bm = 32; bn = 32; pl.bkp = 128; }
   pl.tiles_m = bg::cdiv(Ci, bm);
   pl.tiles_n = bg::cdiv(Co, bn);
-  const long base = (long)pl.tiles_m * pl.tiles_n * k * k;
-  long want = std::max(1L, (1024 + base - 1) / base);           // aim for >= 1024 workgroups
+  pl.taps_in_grid = 1;
+  }
+  const long base = (long)pl.tiles_m * pl.tiles_n * (pl.taps_in_grid ? kk : 1);
+  long want = std::max(1L, (768 + base - 1) / base);            // aim for ~3 workgroups per CU
   long steps = (M + pl.bkp - 1) / pl.bkp;
   want = std::min(want, std::max(1L, steps / 4));               // at least 4 K-steps per workgroup
+  if ((size_t)kk * Ci * Co * sizeof(float) > (8u << 20)) want = std::min(want, 2L);   // big slabs: the reduce pass costs more than idle CUs
   long chunk = ((M + want - 1) / want + pl.bkp - 1) / pl.bkp * pl.bkp;
   pl.chunk = (int)chunk;
   pl.ksplit = (int)((M + chunk - 1) / chunk);
@@ -298,22 +427,32 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     hipLaunchKernelGGL(wgrad_direct_kernel, dim3(bg::cdiv(nout, 256), pl.ksplit), dim3(256), 0, L.s, p);
     rc = L.done("wgrad_direct_kernel");
   } else {
-    dim3 grid(pl.tiles_m * pl.tiles_n, ksize * ksize, pl.ksplit);
-    bg::Launch L(stream, "conv_wgrad_mfma", flops, 0);
+    dim3 grid(pl.tiles_m * pl.tiles_n, pl.taps_in_grid ? ksize * ksize : 1, pl.ksplit);
+    bg::Launch L(stream, pl.mode >= 20 ? "conv_wgrad_mfma_thin_co" : (pl.mode >= 10 ? "conv_wgrad_mfma_thin_ci" : "conv_wgrad_mfma"), flops, 0);
     switch (pl.mode) {
-      case 1: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 32, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
-      case 2: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 32, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
-      case 3: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64, 2, 1, 2>), grid, dim3(256), 0, L.s, p); break;
-      case 4: hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 64, 1, 2, 2>), grid, dim3(256), 0, L.s, p); break;
-      default: hipLaunchKernelGGL((conv_wgrad_kernel<32, 32, 128, 1, 1, 4>), grid, dim3(256), 0, L.s, p); break;
+      case 1: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 32, 2, 2, 1, 0>), grid, dim3(256), 0, L.s, p); break;
+      case 2: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 32, 2, 2, 1, 0>), grid, dim3(256), 0, L.s, p); break;
+      case 3: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64, 2, 1, 2, 0>), grid, dim3(256), 0, L.s, p); break;
+      case 4: hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 64, 1, 2, 2, 0>), grid, dim3(256), 0, L.s, p); break;
+      case 5: hipLaunchKernelGGL((conv_wgrad_kernel<32, 32, 128, 1, 1, 4, 0>), grid, dim3(256), 0, L.s, p); break;
+      case 10: hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 64, 1, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
+      case 11: hipLaunchKernelGGL((conv_wgrad_kernel<96, 32, 64, 1, 1, 4, 1>), grid, dim3(256), 0, L.s, p); break;
+      case 12: hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 64, 1, 1, 4, 1>), grid, dim3(256), 0, L.s, p); break;
+      case 20: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64, 2, 1, 2, 2>), grid, dim3(256), 0, L.s, p); break;
+      case 21: hipLaunchKernelGGL((conv_wgrad_kernel<32, 96, 64, 1, 1, 4, 2>), grid, dim3(256), 0, L.s, p); break;
+      default: hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 64, 1, 1, 4, 2>), grid, dim3(256), 0, L.s, p); break;
     }
     rc = L.done("conv_wgrad_kernel");
   }
   if (rc) return rc;
   if (pl.ksplit > 1) {
     bg::Launch L(stream, "conv_wgrad_reduce", 0, (double)(pl.ksplit + 1) * nout * 4);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bg::cdiv(nout, 256)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,
-                       (int)nout, pl.ksplit, beta, scale);
+    if (nout % 4 == 0 && bg::aligned16(ws_d))
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bg::cdiv(nout / 4, 256)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,
+                         (int)nout, pl.ksplit, beta, scale);
+    else
+      hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(bg::cdiv(nout, 256)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,
+                         (int)nout, pl.ksplit, beta, scale);
     rc = L.done("wgrad_reduce_kernel");
   }
   return rc;

@@ -33,6 +33,65 @@ __global__ __launch_bounds__(kT) void gemm_naive_kernel(const float* __restrict_
   }
 }
 
+// LDS-tiled SGEMM, 64x64 tile, 16-deep steps, 4x4 outputs per thread (generator's Dense(100 -> 8192) and its
+// weight gradient).  Small problem (0.4 GFLOP): the point is coalesced operand reads, not the MFMA.
+__global__ __launch_bounds__(kT) void gemm_tiled_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
+                                                        float* __restrict__ C, int M, int N, int K, int transA, int transB,
+                                                        const float* __restrict__ bias, float beta, float scale) {
+  __shared__ float As[16][64 + 4], Bs[16][64 + 4];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    // A tile -> As[k][m]; B tile -> Bs[k][n]; 1024 elements each, 4 per thread
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = threadIdx.x + i * kT;
+      int kk, mm;
+      if (transA) { kk = e >> 6; mm = e & 63; } else { mm = e >> 4; kk = e & 15; }   // contiguous index fastest
+      const int m = m0 + mm, k = k0 + kk;
+      As[kk][mm] = (m < M && k < K) ? (transA ? A[(size_t)k * M + m] : A[(size_t)m * K + k]) : 0.f;
+      int kb, nn;
+      if (transB) { nn = e >> 4; kb = e & 15; } else { kb = e >> 6; nn = e & 63; }
+      const int n = n0 + nn, k2 = k0 + kb;
+      Bs[kb][nn] = (n < N && k2 < K) ? (transB ? Bm[(size_t)n * K + k2] : Bm[(size_t)k2 * N + n]) : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      float a[4], b[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + tx * 4 + j;
+      if (n >= N) continue;
+      float v = scale * acc[i][j];
+      if (bias) v += bias[n];
+      const size_t e = (size_t)m * N + n;
+      if (beta != 0.f) v += beta * C[e];
+      C[e] = v;
+    }
+  }
+}
+
 // N == 1, no transposes: one wave per row (critic's Dense(2048 -> 1))
 __global__ __launch_bounds__(kT) void rowdot_kernel(const float* __restrict__ A, const float* __restrict__ w, float* __restrict__ C,
                                                     int M, int K, const float* __restrict__ bias, float beta, float scale) {
@@ -78,6 +137,83 @@ __device__ inline void col_reduce(F f, int M, int N, float* partial) {
   }
 }
 
+// Fast path for C a power of two in [4, 1024]: the matrix is swept as a flat float4 stream, so every lane moves
+// 16 B whatever C is; a thread's four channels are fixed ((4*tid) mod C) because 1024 mod C == 0.
+template <int NQ, class F>
+__device__ inline void flat_reduce(F f, int M, int C, float* partial) {
+  __shared__ float4 red[NQ][kT];
+  const int rows_per = (M + gridDim.x - 1) / gridDim.x;
+  const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
+  const int G = C >> 2;                           // distinct channel quads
+  float4 acc[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) acc[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (r1 > r0) {
+    const size_t base4 = (size_t)r0 * G, total4 = (size_t)(r1 - r0) * G;
+    const int c4 = (threadIdx.x % G) * 4;
+    for (size_t q4 = threadIdx.x; q4 < total4; q4 += kT) f(base4 + q4, c4, acc);
+  }
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) red[q][threadIdx.x] = acc[q];
+  __syncthreads();
+  if ((int)threadIdx.x < G) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      float4 s = red[q][threadIdx.x];
+      for (int t = threadIdx.x + G; t < kT; t += G) {
+        const float4 v = red[q][t];
+        s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+      }
+      *reinterpret_cast<float4*>(partial + ((size_t)blockIdx.x * NQ + q) * C + threadIdx.x * 4) = s;
+    }
+  }
+}
+
+inline bool flat_ok(int M, int C) { return C >= 4 && C <= 1024 && (C & (C - 1)) == 0 && M >= 64; }
+inline int flat_blocks(int M, int C) {
+  const size_t total4 = (size_t)M * C / 4;
+  return (int)std::max<size_t>(1, std::min<size_t>({(size_t)512, total4 / (kT * 8), (size_t)M}));
+}
+
+__global__ __launch_bounds__(kT) void colsum_flat_kernel(const float* __restrict__ x, int M, int C, int square, float* partial) {
+  flat_reduce<1>([&](size_t q4, int, float4* a) {
+    const float4 v = reinterpret_cast<const float4*>(x)[q4];
+    if (square) { a[0].x = fmaf(v.x, v.x, a[0].x); a[0].y = fmaf(v.y, v.y, a[0].y); a[0].z = fmaf(v.z, v.z, a[0].z); a[0].w = fmaf(v.w, v.w, a[0].w); }
+    else { a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w; }
+  }, M, C, partial);
+}
+
+__global__ __launch_bounds__(kT) void bn_stats_flat_kernel(const float* __restrict__ x, int M, int C, float* partial) {
+  flat_reduce<2>([&](size_t q4, int, float4* a) {
+    const float4 v = reinterpret_cast<const float4*>(x)[q4];
+    a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
+    a[1].x = fmaf(v.x, v.x, a[1].x); a[1].y = fmaf(v.y, v.y, a[1].y); a[1].z = fmaf(v.z, v.z, a[1].z); a[1].w = fmaf(v.w, v.w, a[1].w);
+  }, M, C, partial);
+}
+
+__global__ __launch_bounds__(kT) void bn_bwd_flat_kernel(const float* __restrict__ dy, const float* __restrict__ y,
+                                                         const float* __restrict__ x, int M, int C, const float* __restrict__ mean,
+                                                         const float* __restrict__ inv, float alpha, float* partial) {
+  flat_reduce<2>([&](size_t q4, int c4, float4* a) {
+    const float4 d = reinterpret_cast<const float4*>(dy)[q4], yy = reinterpret_cast<const float4*>(y)[q4],
+                 xx = reinterpret_cast<const float4*>(x)[q4];
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c4), iv = *reinterpret_cast<const float4*>(inv + c4);
+    const float dz0 = d.x * (yy.x > 0.f ? 1.f : alpha), dz1 = d.y * (yy.y > 0.f ? 1.f : alpha);
+    const float dz2 = d.z * (yy.z > 0.f ? 1.f : alpha), dz3 = d.w * (yy.w > 0.f ? 1.f : alpha);
+    a[0].x += dz0; a[0].y += dz1; a[0].z += dz2; a[0].w += dz3;
+    a[1].x = fmaf(dz0, (xx.x - mu.x) * iv.x, a[1].x); a[1].y = fmaf(dz1, (xx.y - mu.y) * iv.y, a[1].y);
+    a[1].z = fmaf(dz2, (xx.z - mu.z) * iv.z, a[1].z); a[1].w = fmaf(dz3, (xx.w - mu.w) * iv.w, a[1].w);
+  }, M, C, partial);
+}
+
+// one wave per channel sums the per-block partials: partial[(b*NQ + q)*C + c]
+__device__ inline float wave_sum_partials(const float* __restrict__ partial, int nblk, int NQ, int q, int C, int c) {
+  float s = 0.f;
+  for (int b = threadIdx.x & 63; b < nblk; b += 64) s += partial[((size_t)b * NQ + q) * C + c];
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  return __shfl(s, 0, 64);
+}
+
 __global__ __launch_bounds__(kT) void colsum_partial_kernel(const float* __restrict__ x, int M, int N, int square, float* partial) {
   col_reduce<1>([&](int m, int n, float* a) {
     const float v = x[(size_t)m * N + n];
@@ -87,14 +223,14 @@ __global__ __launch_bounds__(kT) void colsum_partial_kernel(const float* __restr
 
 __global__ __launch_bounds__(kT) void colsum_final_kernel(const float* __restrict__ partial, int nblk, int N, float* out, float beta,
                                                           float scale) {
-  const int n = blockIdx.x * kT + threadIdx.x;
+  const int n = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
   if (n >= N) return;
-  float s = 0.f;
-  for (int b = 0; b < nblk; ++b) s += partial[(size_t)b * N + n];
-  out[n] = (beta != 0.f ? beta * out[n] : 0.f) + scale * s;
+  const float s = wave_sum_partials(partial, nblk, 1, 0, N, n);
+  if ((threadIdx.x & 63) == 0) out[n] = (beta != 0.f ? beta * out[n] : 0.f) + scale * s;
 }
 
 int col_blocks(int M) { return std::max(1, std::min(kColBlocks, M / 16)); }
+int red_blocks(int M, int C) { return flat_ok(M, C) ? flat_blocks(M, C) : col_blocks(M); }
 
 // ---------------------------------------------------------------- BatchNormalization + LeakyReLU
 __global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const float* __restrict__ x, int M, int C, float* partial) {
@@ -108,13 +244,10 @@ __global__ __launch_bounds__(kT) void bn_stats_partial_kernel(const float* __res
 __global__ __launch_bounds__(kT) void bn_stats_final_kernel(const float* __restrict__ partial, int nblk, int M, int C, float* save_mean,
                                                             float* save_inv, float* moving_mean, float* moving_var, float eps,
                                                             float momentum, int unbiased) {
-  const int c = blockIdx.x * kT + threadIdx.x;
+  const int c = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
   if (c >= C) return;
-  float s = 0.f, s2 = 0.f;
-  for (int b = 0; b < nblk; ++b) {
-    s += partial[((size_t)b * 2 + 0) * C + c];
-    s2 += partial[((size_t)b * 2 + 1) * C + c];
-  }
+  const float s = wave_sum_partials(partial, nblk, 2, 0, C, c), s2 = wave_sum_partials(partial, nblk, 2, 1, C, c);
+  if ((threadIdx.x & 63) != 0) return;
   const float mean = s / (float)M;
   const float var = fmaxf(s2 / (float)M - mean * mean, 0.f);
   save_mean[c] = mean;
@@ -152,13 +285,10 @@ __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(const float* __restr
 }
 
 __global__ __launch_bounds__(kT) void bn_bwd_final_kernel(const float* __restrict__ partial, int nblk, int C, float* dgamma, float* dbeta) {
-  const int c = blockIdx.x * kT + threadIdx.x;
+  const int c = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
   if (c >= C) return;
-  float s = 0.f, s2 = 0.f;
-  for (int b = 0; b < nblk; ++b) {
-    s += partial[((size_t)b * 2 + 0) * C + c];
-    s2 += partial[((size_t)b * 2 + 1) * C + c];
-  }
+  const float s = wave_sum_partials(partial, nblk, 2, 0, C, c), s2 = wave_sum_partials(partial, nblk, 2, 1, C, c);
+  if ((threadIdx.x & 63) != 0) return;
   dbeta[c] = s;
   dgamma[c] = s2;
 }
@@ -362,6 +492,11 @@ int bg_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, 
     hipLaunchKernelGGL(rowdot_kernel, dim3(bg::cdiv(M, kT / 64)), dim3(kT), 0, L.s, A, Bm, C, M, K, bias, beta, scale);
     return L.done("rowdot_kernel");
   }
+  if ((size_t)M * N >= 4096 && K >= 8) {
+    bg::Launch L(stream, "dense_gemm_tiled", flops, 0);
+    hipLaunchKernelGGL(gemm_tiled_kernel, dim3(bg::cdiv(N, 64), bg::cdiv(M, 64)), dim3(kT), 0, L.s, A, Bm, C, M, N, K, transA, transB, bias, beta, scale);
+    return L.done("gemm_tiled_kernel");
+  }
   bg::Launch L(stream, "dense_gemm", flops, 0);
   hipLaunchKernelGGL(gemm_naive_kernel, dim3(grid_for((size_t)M * N)), dim3(kT), 0, L.s, A, Bm, C, M, N, K, transA, transB, bias, beta, scale);
   return L.done("gemm_naive_kernel");
@@ -369,7 +504,7 @@ int bg_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, 
 
 size_t bg_colsum_workspace_bytes(int M, int N) {
   if (M <= 0 || N <= 0) return 0;
-  return (size_t)col_blocks(M) * 2 * N * sizeof(float);
+  return (size_t)std::max(col_blocks(M), 512) * 2 * N * sizeof(float);
 }
 
 int bg_colsum_f32(const float* x, float* out, int M, int N, int square, float beta, float scale, void* ws_d, size_t ws_bytes,
@@ -377,16 +512,17 @@ int bg_colsum_f32(const float* x, float* out, int M, int N, int square, float be
   BG_REQUIRE(x && out, BG_ERR_NULL, "bg_colsum_f32: null pointer");
   BG_REQUIRE(M > 0 && N > 0, BG_ERR_BAD_SHAPE, "bg_colsum_f32: M=%d N=%d", M, N);
   BG_REQUIRE(ws_d && ws_bytes >= bg_colsum_workspace_bytes(M, N), BG_ERR_WORKSPACE, "bg_colsum_f32: workspace too small");
-  const int nblk = col_blocks(M);
+  const int nblk = red_blocks(M, N);
   float* partial = static_cast<float*>(ws_d);
   {
     bg::Launch L(stream, "colsum_partial", 0, 4.0 * M * N);
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, bg::cdiv(N, 64)), dim3(kT), 0, L.s, x, M, N, square, partial);
+    if (flat_ok(M, N) && bg::aligned16(x)) hipLaunchKernelGGL(colsum_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, x, M, N, square, partial);
+    else hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, bg::cdiv(N, 64)), dim3(kT), 0, L.s, x, M, N, square, partial);
     int rc = L.done("colsum_partial_kernel");
     if (rc) return rc;
   }
   bg::Launch L(stream, "colsum_final", 0, 0);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(bg::cdiv(N, kT)), dim3(kT), 0, L.s, partial, nblk, N, out, beta, scale);
+  hipLaunchKernelGGL(colsum_final_kernel, dim3(bg::cdiv(N, kT / 64)), dim3(kT), 0, L.s, partial, nblk, N, out, beta, scale);
   return L.done("colsum_final_kernel");
 }
 
@@ -399,18 +535,19 @@ int bg_bn_train_fwd(const float* x, float* y, int M, int C, const float* gamma, 
   BG_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), BG_ERR_NULL, "bg_bn_train_fwd: moving_mean/var must both be given or both NULL");
   BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_train_fwd: M=%d C=%d", M, C);
   BG_REQUIRE(ws_d && ws_bytes >= bg_bn_workspace_bytes(M, C), BG_ERR_WORKSPACE, "bg_bn_train_fwd: workspace too small");
-  const int nblk = col_blocks(M);
+  const int nblk = red_blocks(M, C);
   float* partial = static_cast<float*>(ws_d);
   const size_t total = (size_t)M * C;
   {
     bg::Launch L(stream, "bn_stats_partial", 0, 4.0 * total);
-    hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, x, M, C, partial);
+    if (flat_ok(M, C) && bg::aligned16(x)) hipLaunchKernelGGL(bn_stats_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, x, M, C, partial);
+    else hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, x, M, C, partial);
     int rc = L.done("bn_stats_partial_kernel");
     if (rc) return rc;
   }
   {
     bg::Launch L(stream, "bn_stats_final", 0, 0);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, partial, nblk, M, C, save_mean, save_inv,
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, nblk, M, C, save_mean, save_inv,
                        moving_mean, moving_var, eps, momentum, unbiased);
     int rc = L.done("bn_stats_final_kernel");
     if (rc) return rc;
@@ -438,19 +575,22 @@ int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, 
   BG_REQUIRE(dy && y && x && dx && gamma && save_mean && save_inv && dgamma && dbeta, BG_ERR_NULL, "bg_bn_train_bwd: null pointer");
   BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_train_bwd: M=%d C=%d", M, C);
   BG_REQUIRE(ws_d && ws_bytes >= bg_bn_workspace_bytes(M, C), BG_ERR_WORKSPACE, "bg_bn_train_bwd: workspace too small");
-  const int nblk = col_blocks(M);
+  const int nblk = red_blocks(M, C);
   float* partial = static_cast<float*>(ws_d);
   const size_t total = (size_t)M * C;
   {
     bg::Launch L(stream, "bn_bwd_partial", 0, 12.0 * total);
-    hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv,
-                       lrelu_alpha, partial);
+    if (flat_ok(M, C) && bg::aligned16(dy) && bg::aligned16(y) && bg::aligned16(x) && bg::aligned16(save_mean) && bg::aligned16(save_inv))
+      hipLaunchKernelGGL(bn_bwd_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv, lrelu_alpha, partial);
+    else
+      hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv,
+                         lrelu_alpha, partial);
     int rc = L.done("bn_bwd_partial_kernel");
     if (rc) return rc;
   }
   {
     bg::Launch L(stream, "bn_bwd_final", 0, 0);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, partial, nblk, C, dgamma, dbeta);
+    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, nblk, C, dgamma, dbeta);
     int rc = L.done("bn_bwd_final_kernel");
     if (rc) return rc;
   }

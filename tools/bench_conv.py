@@ -1,0 +1,73 @@
+#!/usr/bin/env python
+"""Per-layer micro-benchmark of the conv kernels at the C2 (celeba64, B=256) layer shapes: forward, data-gradient and
+filter-gradient of every layer, timed with the library's own HIP-event hooks.  Usage: python tools/bench_conv.py [--arch celeba64]"""
+import argparse
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+from blurred_gan_amd import ops  # noqa: E402
+
+LAYERS = {  # (name, B-mult, H, W, Cin, Cout, stride): conv geometry (H,W,Cin = conv input side)
+    "celeba64": [("D1 3->32", 64, 64, 3, 32, 2), ("D2 32->64", 32, 32, 32, 64, 2), ("D3 64->128", 16, 16, 64, 128, 2),
+                 ("D4 128->256", 8, 8, 128, 256, 2), ("D5 256->512", 4, 4, 256, 512, 2),
+                 # generator ConvT layers expressed as the underlying conv (input side = ConvT output)
+                 ("G1 CT512->512 s1", 4, 4, 512, 512, 1), ("G2 CT512->256", 8, 8, 256, 512, 2), ("G3 CT256->128", 16, 16, 128, 256, 2),
+                 ("G4 CT128->64", 32, 32, 64, 128, 2), ("G5 CT64->32", 64, 64, 32, 64, 2), ("G6 conv32->3", 64, 64, 32, 3, 1)],
+}
+
+
+def run(fn, iters):
+    fn()
+    torch.cuda.synchronize()
+    ops.prof_reset()
+    ops.prof_enable(True)
+    for _ in range(iters):
+        fn()
+    torch.cuda.synchronize()
+    recs = ops.prof_records()
+    ops.prof_enable(False)
+    ops.prof_reset()
+    ms = sum(r[1] for r in recs) / iters
+    fl = sum(r[2] for r in recs) / iters
+    names = sorted({r[0] for r in recs})
+    return ms, fl, names
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--arch", default="celeba64")
+    ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    B = a.batch
+    torch.manual_seed(0)
+    print(f"{'layer':<20}{'op':<8}{'ms':>9}{'TFLOP/s':>10}{'%peak':>8}  kernels")
+    tot = {}
+    for name, H, W, Ci, Co, s in LAYERS[a.arch]:
+        if a.only and a.only not in name:
+            continue
+        Ho, Wo = -(-H // s), -(-W // s)
+        x = torch.rand(B, H, W, Ci, device="cuda") - 0.5
+        dy = torch.rand(B, Ho, Wo, Co, device="cuda") - 0.5
+        w = torch.rand(5, 5, Ci, Co, device="cuda") - 0.5
+        wT = ops.transpose_last2(w, torch.empty(w.numel(), device="cuda"), 25, Ci, Co)
+        y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
+        nb = ops.conv2d_bwd_filter_workspace_bytes(B, H, W, Ci, Co, 5, s)
+        ws = torch.empty(nb // 4 + 4, device="cuda") if nb else None
+        for op, fn in (("fwd", lambda: ops.conv2d_fwd(x, wT, y, 5, s)), ("dgrad", lambda: ops.conv2d_bwd_data(dy, w, dx, 5, s)),
+                       ("wgrad", lambda: ops.conv2d_bwd_filter(x, dy, dw, 5, s, 0.0, 1.0, ws))):
+            ms, fl, names = run(fn, a.iters)
+            tf = fl / (ms * 1e-3) / 1e12
+            tot.setdefault(op, [0.0, 0.0])
+            tot[op][0] += ms
+            tot[op][1] += fl
+            print(f"{name:<20}{op:<8}{ms:9.4f}{tf:10.2f}{100 * tf / 157.3:8.1f}  {','.join(names)}")
+    for op, (ms, fl) in tot.items():
+        print(f"{'TOTAL':<20}{op:<8}{ms:9.4f}{fl / (ms * 1e-3) / 1e12:10.2f}{100 * fl / (ms * 1e-3) / 1e12 / 157.3:8.1f}")
+
+
+if __name__ == "__main__":
+    main()
