@@ -29,6 +29,7 @@ struct GatherParams {
   int B, Hs, Ws, Ck;
   int Hd, Wd, N;
   int ss, ds;          // source / destination stride multipliers
+  unsigned a_bytes, w_bytes;   // operand sizes for the buffer descriptors of the MFMA kernel
   int nphase;
   // epilogue
   int epi_mode;

@@ -14,6 +14,7 @@
 //                       of 16); used by small test geometries only.
 #include "conv_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -38,7 +39,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GatherParams p) {
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
   constexpr int MI = WTM / 32, NI = WTN / 32;
   static_assert(MI >= 1 && NI >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
-  constexpr int STAGE = (BM + BN) * LD;
+  static_assert(BM % RPP == 0, "A loader passes must tile BM exactly (branch-free stores)");
+  constexpr int BROWS = BP * RPP;             // B rows held in LDS (>= BN) so every loader thread stores unconditionally
+  constexpr int STAGE = (BM + BROWS) * LD;
 
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
   __shared__ int rowdst[BM];
@@ -52,14 +55,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GatherParams p) {
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
-  // ---- loader bookkeeping
+  // ---- loader bookkeeping.  Operands come through buffer descriptors: 32-bit byte offsets (cheap address
+  // maths) and the hardware range check returns 0 for the offsets we poison (zero padding, rows past M,
+  // channels past N) -- no clamps, no selects, no branches in the loop body.
+  constexpr unsigned kOob = 0x80000000u;                  // >= num_records: tensors are < 2 GiB (checked on the host)
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wt), 0, (int)p.w_bytes, 0x00020000);
   const int lrow = tid / TPR, lq = tid % TPR;
-  RowAnchor ra[AP];
+  int a_y[AP], a_x[AP];
+  unsigned a_off[AP], b_off[BP];
 #pragma unroll
   for (int i = 0; i < AP; ++i) {
+    RowAnchor ra;
     int dst;
-    const int r = lrow + i * RPP;
-    bg::decode_row(p, g, (r < BM) ? m0 + r : Mph, Mph, ra[i], dst);
+    bg::decode_row(p, g, m0 + lrow + i * RPP, Mph, ra, dst);
+    a_y[i] = ra.ay;
+    a_x[i] = ra.ax;
+    a_off[i] = (unsigned)(((ra.b * p.Hs + ra.ay) * p.Ws + ra.ax) * p.Ck + lq * 4) * 4u;   // garbage for invalid rows: never used
+  }
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    const int n = n0 + lrow + i * RPP;
+    b_off[i] = n < p.N ? (unsigned)(n * p.Ck + lq * 4) * 4u : kOob;
   }
   if (tid < BM) {
     RowAnchor tmp;
@@ -72,41 +89,33 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GatherParams p) {
   const int nsteps = g.ntaps * kchunks;
   float4 regA[AP], regB[BP];
 
+  // Software pipeline (one barrier per step, loop body is a single basic block so the scheduler can slot the
+  // loader's VALU / VMEM / DS-write work between MFMAs):
+  //   step s:  MFMA(first half of tile s) | ds_write tile s+1 (its global loads were issued during step s-1)
+  //            | issue global loads of tile s+2 | MFMA(second half of tile s) | barrier
   auto gload = [&](int step) {
-    const int t = step / kchunks;
-    const int c0 = (step - t * kchunks) * BK + lq * 4;
-    const int tp = g.tap[t];
-    const int dy = bg::tap_dy(tp), dx = bg::tap_dx(tp), wi = bg::tap_wi(tp);
+    const int tq = step / kchunks;
+    const int tp = g.tap[min(tq, g.ntaps - 1)];              // steps past the end re-load the last tap; never consumed
+    const int c0 = (step - tq * kchunks) * BK;
+    const int dy = bg::tap_dy(tp), dx = bg::tap_dx(tp);
+    const unsigned tapoff = (unsigned)(((dy * p.Ws + dx) * p.Ck + c0) * 4);
+    const unsigned woff = (unsigned)((bg::tap_wi(tp) * p.N * p.Ck + c0) * 4);
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const int sy = ra[i].ay + dy, sx = ra[i].ax + dx;
-      const bool ok = (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (ok) v = *reinterpret_cast<const float4*>(p.A + ((size_t)(ra[i].b * p.Hs + sy) * p.Ws + sx) * p.Ck + c0);
-      regA[i] = v;
+      const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)p.Hs && (unsigned)(a_x[i] + dx) < (unsigned)p.Ws;
+      regA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_off[i] + tapoff : kOob, 0, 0));
     }
 #pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      const int r = lrow + i * RPP;
-      const int n = n0 + r;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (r < BN && n < p.N) v = *reinterpret_cast<const float4*>(p.Wt + ((size_t)wi * p.N + n) * p.Ck + c0);
-      regB[i] = v;
-    }
+    for (int i = 0; i < BP; ++i)
+      regB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i] == kOob ? kOob : b_off[i] + woff, 0, 0));
   };
   auto lstore = [&](int buf) {
     float* sa = smem + buf * STAGE;
     float* sb = sa + BM * LD;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) {
-      const int r = lrow + i * RPP;
-      if (r < BM) *reinterpret_cast<float4*>(sa + r * LD + lq * 4) = regA[i];
-    }
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<float4*>(sa + (lrow + i * RPP) * LD + lq * 4) = regA[i];
 #pragma unroll
-    for (int i = 0; i < BP; ++i) {
-      const int r = lrow + i * RPP;
-      if (r < BN) *reinterpret_cast<float4*>(sb + r * LD + lq * 4) = regB[i];
-    }
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<float4*>(sb + (lrow + i * RPP) * LD + lq * 4) = regB[i];
   };
 
   floatx16 acc[MI][NI];
@@ -119,32 +128,48 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GatherParams p) {
 
   gload(0);
   lstore(0);
+  gload(1);
   __syncthreads();
 
   const int frow = lane & 31, fk = (lane >> 5) * 4;
+  const float* sa0 = smem + (wm * WTM + frow) * LD + fk;
+  const float* sb0 = smem + BM * LD + (wn * WTN + frow) * LD + fk;
+  constexpr int KO = BK / 8;
   for (int step = 0; step < nsteps; ++step) {
     const int cur = step & 1;
-    if (step + 1 < nsteps) gload(step + 1);
-    const float* sa = smem + cur * STAGE + (wm * WTM + frow) * LD + fk;
-    const float* sb = smem + cur * STAGE + BM * LD + (wn * WTN + frow) * LD + fk;
+    const float* sa = sa0 + cur * STAGE;
+    const float* sb = sb0 + cur * STAGE;
+    // fragments (4 k's per b128 read) are fetched one k-octet ahead of the MFMAs that consume them
+    float4 af[2][MI], bf[2][NI];
 #pragma unroll
-    for (int ko = 0; ko < BK / 8; ++ko) {
-      float4 af[MI], bf[NI];
+    for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const float4*>(sa + i * 32 * LD);
 #pragma unroll
-      for (int i = 0; i < MI; ++i) af[i] = *reinterpret_cast<const float4*>(sa + i * 32 * LD + ko * 8);
+    for (int j = 0; j < NI; ++j) bf[0][j] = *reinterpret_cast<const float4*>(sb + j * 32 * LD);
 #pragma unroll
-      for (int j = 0; j < NI; ++j) bf[j] = *reinterpret_cast<const float4*>(sb + j * 32 * LD + ko * 8);
+    for (int ko = 0; ko < KO; ++ko) {
+      const int c = ko & 1, n = c ^ 1;
+      if (ko + 1 < KO) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[n][i] = *reinterpret_cast<const float4*>(sa + i * 32 * LD + (ko + 1) * 8);
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf[n][j] = *reinterpret_cast<const float4*>(sb + j * 32 * LD + (ko + 1) * 8);
+      }
+      if (ko == KO / 2) {
+        lstore(cur ^ 1);
+        gload(step + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (see conv_wgrad.hip)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].x, bf[c][j].x, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].y, bf[c][j].y, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].z, bf[c][j].z, acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].w, bf[c][j].w, acc[i][j], 0, 0, 0);
         }
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (step + 1 < nsteps) lstore(cur ^ 1);
     __syncthreads();
   }
 
@@ -483,11 +508,23 @@ int launch_igemm(const GatherParams& p, void* stream, const char* name) {
 template <int BK>
 int dispatch_igemm(const GatherParams& p, void* stream, const char* tag) {
   const int Mmax = max_phase_m(p);
+  // Pick the tile that keeps >= 2 workgroups per CU resident (two waves per SIMD: one issues MFMAs while the
+  // other runs its loader segment); bigger tiles only when the grid still fills the chip twice over.
   auto wgs = [&](int bm, int bn) { return (long)bg::cdiv(Mmax, bm) * bg::cdiv(p.N, bn) * p.nphase; };
-  if (p.N > 64 && wgs(128, 128) >= 256) return launch_igemm<128, 128, BK, 2, 2>(p, stream, tag);
-  if (p.N > 32 && wgs(128, 64) >= 256) return launch_igemm<128, 64, BK, 2, 2>(p, stream, tag);
-  if (p.N <= 32) return launch_igemm<128, 32, BK, 4, 1>(p, stream, tag);
-  return launch_igemm<64, 64, BK, 2, 2>(p, stream, tag);
+  const long kFull = 2 * 256;
+  static const int force = getenv("BG_IGEMM_TILE") ? atoi(getenv("BG_IGEMM_TILE")) : 0;   // tuning aid: 1..4
+  int pick;
+  if (force) pick = force;
+  else if (p.N <= 32) pick = 3;
+  else if (wgs(64, 64) <= 4 * kFull || p.N < 128) pick = 4;      // measured: 64x64 at 4 WGs/CU beats the larger tiles
+  else pick = 4;
+  if (pick == 3 && p.N > 32) pick = 2;
+  switch (pick) {
+    case 1: return launch_igemm<128, 128, BK, 2, 2>(p, stream, tag);
+    case 2: return launch_igemm<128, 64, BK, 2, 2>(p, stream, tag);
+    case 3: return launch_igemm<128, 32, BK, 4, 1>(p, stream, tag);
+    default: return launch_igemm<64, 64, BK, 2, 2>(p, stream, tag);
+  }
 }
 
 int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char* tag) {
@@ -502,9 +539,17 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
   BG_REQUIRE((size_t)p.B * p.Hd * p.Wd * (size_t)p.N < (1ull << 31) && (size_t)p.B * p.Hs * p.Ws * (size_t)p.Ck < (1ull << 31),
              BG_ERR_UNSUPPORTED, "%s: tensor exceeds 2^31 elements", tag);
   char name[96];
-  if (p.Ck % 16 == 0 && p.N > 4) {
+  const size_t a_bytes = (size_t)p.B * p.Hs * p.Ws * p.Ck * sizeof(float);
+  int ntap_w = 0;
+  for (int i = 0; i < p.nphase; ++i)
+    for (int t = 0; t < p.ph[i].ntaps; ++t) ntap_w = std::max(ntap_w, bg::tap_wi(p.ph[i].tap[t]) + 1);
+  const size_t w_bytes = (size_t)ntap_w * p.N * p.Ck * sizeof(float);
+  if (p.Ck % 16 == 0 && p.N > 4 && a_bytes < (1ull << 31) && w_bytes < (1ull << 31)) {
+    p.a_bytes = (unsigned)a_bytes;
+    p.w_bytes = (unsigned)w_bytes;
     snprintf(name, sizeof name, "conv_igemm_%s", tag);
-    return (p.Ck % 32 == 0) ? dispatch_igemm<32>(p, stream, name) : dispatch_igemm<16>(p, stream, name);
+    static const int force_bk = getenv("BG_IGEMM_BK") ? atoi(getenv("BG_IGEMM_BK")) : 0;   // tuning aid
+    return (p.Ck % 32 == 0 && force_bk != 16) ? dispatch_igemm<32>(p, stream, name) : dispatch_igemm<16>(p, stream, name);
   }
   if (p.N <= 4 && (p.Ck == 16 || p.Ck == 32 || p.Ck == 64)) {
     // LDS patch kernel: patch = anchor tile + tap halo of the widest phase

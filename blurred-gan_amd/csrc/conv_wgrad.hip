@@ -9,6 +9,7 @@
 //   wgrad_direct_kernel thin / odd channel counts: one thread per (tap, ci, co) output and pixel slice.
 #include "conv_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
@@ -25,7 +26,408 @@ struct WgradParams {
   int ksplit;
   int tiles_n;
   float beta, scale; // applied only when ksplit == 1
+  unsigned x_bytes, dy_bytes;
+  unsigned mul_hw, sh_hw, mul_w, sh_w;   // magic-number division by Ho*Wo and Wo (dividends < 2^31)
 };
+
+// floor(m / d) for m < 2^31 with host-computed (mul, sh): q = (m * mul) >> sh
+__device__ inline int fastdiv(int m, unsigned mul, unsigned sh) { return (int)(((unsigned long long)(unsigned)m * mul) >> sh); }
+
+// Main filter-gradient kernel (grid.y = tap): same pipeline as the forward kernel -- buffer loads with the
+// hardware range check doing the zero padding / tails, branch-free single-block loop body, one barrier per step:
+//   step s: MFMA(first half of chunk s) | ds_write chunk s+1 | issue loads of chunk s+2 | MFMA(second half) | barrier
+template <int BM, int BN, int BKP, int WAVES_M, int WAVES_N, int WAVES_K>
+__global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p) {
+  static_assert(WAVES_M * WAVES_N * WAVES_K == 4, "4 waves");
+  constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
+  constexpr int MI = WTM / 32, NI = WTN / 32;
+  static_assert(MI >= 1 && NI >= 1 && WTM % 32 == 0 && WTN % 32 == 0, "wave tile");
+  constexpr int TPR_A = BM / 4, RPP_A = 256 / TPR_A, AP = BKP / RPP_A;
+  constexpr int TPR_B = BN / 4, RPP_B = 256 / TPR_B, BP = BKP / RPP_B;
+  static_assert(AP >= 1 && BP >= 1 && BKP % RPP_A == 0 && BKP % RPP_B == 0, "loader passes must tile the chunk exactly");
+  constexpr int STAGE = BKP * (BM + BN);
+  constexpr int RED = (WAVES_K > 1) ? (WAVES_K - 1) * WAVES_M * WAVES_N * MI * NI * 1024 : 0;
+  constexpr int SMEM = (2 * STAGE > RED) ? 2 * STAGE : RED;
+  constexpr unsigned kOob = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave % WAVES_K, wmn = wave / WAVES_K;
+  const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
+  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+  const int ci0 = tile_m * BM, co0 = tile_n * BN;
+  const int tap = blockIdx.y;
+  const int kh = tap / p.k, kw = tap % p.k;
+  const int m_begin = blockIdx.z * p.chunk;
+  const int m_end = min(p.M, m_begin + p.chunk);
+  const int nsteps = (m_end - m_begin + BKP - 1) / BKP;
+
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, (int)p.dy_bytes, 0x00020000);
+  const int arow = tid / TPR_A, aq = tid % TPR_A;
+  const int brow = tid / TPR_B, bq = tid % TPR_B;
+  const int HoWo = p.Ho * p.Wo;
+  const bool a_col_ok = ci0 + aq * 4 < p.Ci, b_col_ok = co0 + bq * 4 < p.Co;
+  const int a_coloff = (ci0 + aq * 4) * 4, b_coloff = (co0 + bq * 4) * 4;
+  const int dyk = kh - p.pt, dxk = kw - p.pl;
+  float4 regA[AP], regB[BP];
+
+  // Row state advanced incrementally from chunk to chunk (adds / compares / selects only: integer multiplies and
+  // divisions are quarter-rate VALU ops that would compete with the MFMA issue slots).  Row of pass i is output
+  // pixel m = (b, oh, ow); we keep oh*s, ow*s and the byte offset of x[b, oh*s + dyk, ow*s + dxk, ci0 + 4*aq].
+  const int WoS = p.Wo * p.s, HoS = p.Ho * p.s;
+  int dstep_ow, dstep_oh, dstep_b;
+  {
+    dstep_b = BKP / HoWo;
+    const int r = BKP - dstep_b * HoWo;
+    dstep_oh = r / p.Wo;
+    dstep_ow = r - dstep_oh * p.Wo;
+  }
+  const int d_owS = dstep_ow * p.s, d_ohS = dstep_oh * p.s;
+  const int rowB = p.W * p.Ci * 4;                                     // bytes per x row
+  const int d_off = (dstep_b * p.H + d_ohS) * rowB + d_owS * p.Ci * 4;
+  const int corr_w = p.s * rowB - WoS * p.Ci * 4;                       // ow wrapped: next output row
+  const int corr_h = (p.H - HoS) * rowB;                                // oh wrapped: next image
+  int a_m[AP], a_owS[AP], a_ohS[AP];
+  unsigned a_off[AP], b_off[BP];
+  int b_m[BP];
+#pragma unroll
+  for (int i = 0; i < AP; ++i) {
+    const int m = m_begin + arow + i * RPP_A;
+    const int b = fastdiv(m, p.mul_hw, p.sh_hw);
+    const int rem = m - b * HoWo;
+    const int oh = fastdiv(rem, p.mul_w, p.sh_w);
+    const int ow = rem - oh * p.Wo;
+    a_m[i] = m;
+    a_ohS[i] = oh * p.s;
+    a_owS[i] = ow * p.s;
+    a_off[i] = (unsigned)(((b * p.H + oh * p.s + dyk) * p.W + ow * p.s + dxk) * p.Ci * 4 + a_coloff);
+  }
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    b_m[i] = m_begin + brow + i * RPP_B;
+    b_off[i] = (unsigned)(b_m[i] * p.Co * 4 + b_coloff);
+  }
+  const int b_dstep = BKP * p.Co * 4;
+
+  auto gload = [&](int) {     // loads the NEXT chunk in sequence (called once per step, in order)
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const bool ok = a_col_ok && a_m[i] < m_end && (unsigned)(a_ohS[i] + dyk) < (unsigned)p.H &&
+                      (unsigned)(a_owS[i] + dxk) < (unsigned)p.W;
+      regA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? a_off[i] : kOob, 0, 0));
+      // advance to the same row of the next chunk
+      a_m[i] += BKP;
+      int ow = a_owS[i] + d_owS, oh = a_ohS[i] + d_ohS;
+      unsigned off = a_off[i] + (unsigned)d_off;
+      const bool c1 = ow >= WoS;
+      ow -= c1 ? WoS : 0;
+      oh += c1 ? p.s : 0;
+      off += c1 ? (unsigned)corr_w : 0u;
+      const bool c2 = oh >= HoS;
+      oh -= c2 ? HoS : 0;
+      off += c2 ? (unsigned)corr_h : 0u;
+      a_owS[i] = ow; a_ohS[i] = oh; a_off[i] = off;
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const bool ok = b_col_ok && b_m[i] < m_end;
+      regB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, ok ? b_off[i] : kOob, 0, 0));
+      b_m[i] += BKP;
+      b_off[i] += (unsigned)b_dstep;
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* sa = smem + buf * STAGE;
+    float* sb = sa + BKP * BM;
+#pragma unroll
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<float4*>(sa + (arow + i * RPP_A) * BM + aq * 4) = regA[i];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<float4*>(sb + (brow + i * RPP_B) * BN + bq * 4) = regB[i];
+  };
+
+  floatx16 acc[MI][NI];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  gload(0);
+  lstore(0);
+  gload(1);
+  __syncthreads();
+  const int fcol = lane & 31, fk = lane >> 5;
+  const float* sa0 = smem + wm * WTM + fcol;
+  const float* sb0 = smem + BKP * BM + wn * WTN + fcol;
+  constexpr int ITERS = BKP / 2 / WAVES_K;                 // k-pairs per wave per chunk
+  constexpr int PF = (MI * NI >= 4) ? 1 : (MI * NI >= 2 ? 2 : 4);   // k-pairs per fragment group: >= 4 MFMAs behind every LDS wait
+  constexpr int NG = ITERS / PF;
+  static_assert(ITERS % PF == 0 && NG >= 2, "fragment grouping");
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    const float* sa = sa0 + cur * STAGE;
+    const float* sb = sb0 + cur * STAGE;
+    // Fragment groups are fetched one group ahead of the MFMAs that consume them (register double buffer); the
+    // sched_barrier pins that order -- left alone, the scheduler sinks each ds_read to just before its MFMA and
+    // the LDS latency is exposed once per k-pair.
+    float af[2][PF][MI], bf[2][PF][NI];
+    auto fetch = [&](int slot, int grp) {
+#pragma unroll
+      for (int q = 0; q < PF; ++q) {
+        const int krow = 2 * (wk + (grp * PF + q) * WAVES_K) + fk;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) af[slot][q][i] = sa[krow * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < NI; ++j) bf[slot][q][j] = sb[krow * BN + j * 32];
+      }
+    };
+    fetch(0, 0);
+#pragma unroll
+    for (int grp = 0; grp < NG; ++grp) {
+      const int c = grp & 1;
+      if (grp + 1 < NG) fetch(c ^ 1, grp + 1);
+      if (grp == NG / 2) {
+        lstore(cur ^ 1);
+        gload(step + 2);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < PF; ++q)
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NI; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][q][i], bf[c][q][j], acc[i][j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  if (WAVES_K > 1) {
+    if (wk > 0) {
+      float* red = smem + (((wk - 1) * WAVES_M * WAVES_N + wmn) * MI * NI) * 1024;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((i * NI + j) * 16 + r) * 64 + lane] = acc[i][j][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int w = 1; w < WAVES_K; ++w) {
+      const float* red = smem + (((w - 1) * WAVES_M * WAVES_N + wmn) * MI * NI) * 1024;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] += red[((i * NI + j) * 16 + r) * 64 + lane];
+    }
+  }
+
+  float* out = p.out + (size_t)blockIdx.z * p.k * p.k * p.Ci * p.Co + (size_t)tap * p.Ci * p.Co;
+  const bool direct = p.ksplit == 1;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const int co = co0 + wn * WTN + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int ci = ci0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (ci < p.Ci && co < p.Co) {
+          float* q = out + (size_t)ci * p.Co + co;
+          const float v = acc[i][j][r];
+          if (direct) *q = (p.beta != 0.f ? p.beta * *q : 0.f) + p.scale * v;
+          else *q = v;
+        }
+      }
+    }
+}
+
+// Tap-grouped variant for 32-channel input tiles: one workgroup accumulates the TG = k taps of one kernel row
+// (grid.y = kh) for a 32-wide ci tile.  Each loader thread owns ONE pixel row of the chunk for all TG taps, so the
+// row bookkeeping is paid once per TG tap tiles, the dy tile is shared by the TG taps, and every k-pair feeds
+// TG MFMAs per wave -- the loader VALU per MFMA drops ~4x against the per-tap kernel on 32/64-channel layers.
+template <int TG, int BN, int WAVES_N, int WAVES_K>
+__global__ __launch_bounds__(256) void conv_wgrad_tg_kernel(const WgradParams p) {
+  static_assert(WAVES_N * WAVES_K == 4 && BN == 32 * WAVES_N, "one 32-wide co tile per wave column");
+  constexpr int BKP = 32, BMc = 32, BM = TG * BMc;
+  constexpr int TPR_B = BN / 4, RPP_B = 256 / TPR_B, BP = BKP / RPP_B;
+  static_assert(BP >= 1 && BKP % RPP_B == 0, "B loader");
+  constexpr int STAGE = BKP * (BM + BN);
+  constexpr int RED = (WAVES_K > 1) ? (WAVES_K - 1) * WAVES_N * TG * 1024 : 0;
+  constexpr int SMEM = (2 * STAGE > RED) ? 2 * STAGE : RED;
+  constexpr unsigned kOob = 0x80000000u;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wk = wave % WAVES_K, wn = wave / WAVES_K;
+  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+  const int ci0 = tile_m * BMc, co0 = tile_n * BN;
+  const int kh = blockIdx.y;
+  const int m_begin = blockIdx.z * p.chunk;
+  const int m_end = min(p.M, m_begin + p.chunk);
+  const int nsteps = (m_end - m_begin + BKP - 1) / BKP;
+
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, (int)p.dy_bytes, 0x00020000);
+  const int arow = tid >> 3, aq = tid & 7;                 // one pixel row per thread, 8 float4 across the 32 ci
+  const int brow = tid / TPR_B, bq = tid % TPR_B;
+  const int HoWo = p.Ho * p.Wo;
+  const bool a_col_ok = ci0 + aq * 4 < p.Ci, b_col_ok = co0 + bq * 4 < p.Co;
+  const int dyk = kh - p.pt;
+  const int WoS = p.Wo * p.s, HoS = p.Ho * p.s;
+  const int dstep_b = BKP / HoWo;
+  const int dstep_r = BKP - dstep_b * HoWo;
+  const int dstep_oh = dstep_r / p.Wo, dstep_ow = dstep_r - dstep_oh * p.Wo;
+  const int d_owS = dstep_ow * p.s, d_ohS = dstep_oh * p.s;
+  const int pixB = p.Ci * 4, rowB = p.W * pixB;
+  const int d_off = (dstep_b * p.H + d_ohS) * rowB + d_owS * pixB;
+  const int corr_w = p.s * rowB - WoS * pixB, corr_h = (p.H - HoS) * rowB;
+  int a_m, a_owS, a_ohS;
+  unsigned a_off;                                          // byte offset of x[b, oh*s + dyk, ow*s - pl, ci0 + 4*aq] (tap kw = 0)
+  {
+    const int m = m_begin + arow;
+    const int b = fastdiv(m, p.mul_hw, p.sh_hw);
+    const int rem = m - b * HoWo;
+    const int oh = fastdiv(rem, p.mul_w, p.sh_w);
+    const int ow = rem - oh * p.Wo;
+    a_m = m; a_ohS = oh * p.s; a_owS = ow * p.s;
+    a_off = (unsigned)(((b * p.H + oh * p.s + dyk) * p.W + ow * p.s - p.pl) * pixB + (ci0 + aq * 4) * 4);
+  }
+  int b_m[BP];
+  unsigned b_off[BP];
+#pragma unroll
+  for (int i = 0; i < BP; ++i) {
+    b_m[i] = m_begin + brow + i * RPP_B;
+    b_off[i] = (unsigned)(b_m[i] * p.Co * 4 + (co0 + bq * 4) * 4);
+  }
+  const int b_dstep = BKP * p.Co * 4;
+  float4 regA[TG], regB[BP];
+
+  auto gload = [&]() {
+    const bool row_ok = a_col_ok && a_m < m_end && (unsigned)(a_ohS + dyk) < (unsigned)p.H;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) {
+      const bool ok = row_ok && (unsigned)(a_owS + t - p.pl) < (unsigned)p.W;
+      regA[t] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? a_off + (unsigned)(t * pixB) : kOob, 0, 0));
+    }
+    a_m += BKP;
+    int ow = a_owS + d_owS, oh = a_ohS + d_ohS;
+    unsigned off = a_off + (unsigned)d_off;
+    const bool c1 = ow >= WoS;
+    ow -= c1 ? WoS : 0;
+    oh += c1 ? p.s : 0;
+    off += c1 ? (unsigned)corr_w : 0u;
+    const bool c2 = oh >= HoS;
+    oh -= c2 ? HoS : 0;
+    off += c2 ? (unsigned)corr_h : 0u;
+    a_owS = ow; a_ohS = oh; a_off = off;
+#pragma unroll
+    for (int i = 0; i < BP; ++i) {
+      const bool ok = b_col_ok && b_m[i] < m_end;
+      regB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, ok ? b_off[i] : kOob, 0, 0));
+      b_m[i] += BKP;
+      b_off[i] += (unsigned)b_dstep;
+    }
+  };
+  auto lstore = [&](int buf) {
+    float* sa = smem + buf * STAGE;
+    float* sb = sa + BKP * BM;
+#pragma unroll
+    for (int t = 0; t < TG; ++t) *reinterpret_cast<float4*>(sa + arow * BM + t * BMc + aq * 4) = regA[t];
+#pragma unroll
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<float4*>(sb + (brow + i * RPP_B) * BN + bq * 4) = regB[i];
+  };
+
+  floatx16 acc[TG];
+#pragma unroll
+  for (int t = 0; t < TG; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  gload();
+  lstore(0);
+  gload();
+  __syncthreads();
+  const int fcol = lane & 31, fk = lane >> 5;
+  const float* sa0 = smem + fcol;
+  const float* sb0 = smem + BKP * BM + wn * 32 + fcol;
+  constexpr int ITERS = BKP / 2 / WAVES_K;
+  for (int step = 0; step < nsteps; ++step) {
+    const int cur = step & 1;
+    const float* sa = sa0 + cur * STAGE;
+    const float* sb = sb0 + cur * STAGE;
+    float af[2][TG], bf[2];
+    {
+      const int krow = 2 * wk + fk;
+#pragma unroll
+      for (int t = 0; t < TG; ++t) af[0][t] = sa[krow * BM + t * BMc];
+      bf[0] = sb[krow * BN];
+    }
+#pragma unroll
+    for (int it = 0; it < ITERS; ++it) {
+      const int c = it & 1;
+      if (it + 1 < ITERS) {
+        const int krow = 2 * (wk + (it + 1) * WAVES_K) + fk;
+#pragma unroll
+        for (int t = 0; t < TG; ++t) af[c ^ 1][t] = sa[krow * BM + t * BMc];
+        bf[c ^ 1] = sb[krow * BN];
+      }
+      if (it == ITERS / 2) {
+        lstore(cur ^ 1);
+        gload();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < TG; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][t], bf[c], acc[t], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();
+  }
+
+  if (WAVES_K > 1) {
+    if (wk > 0) {
+      float* red = smem + (((wk - 1) * WAVES_N + wn) * TG) * 1024;
+#pragma unroll
+      for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[(t * 16 + r) * 64 + lane] = acc[t][r];
+    }
+    __syncthreads();
+    if (wk > 0) return;
+#pragma unroll
+    for (int w = 1; w < WAVES_K; ++w) {
+      const float* red = smem + (((w - 1) * WAVES_N + wn) * TG) * 1024;
+#pragma unroll
+      for (int t = 0; t < TG; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] += red[(t * 16 + r) * 64 + lane];
+    }
+  }
+
+  const bool direct = p.ksplit == 1;
+  const int co = co0 + wn * 32 + (lane & 31);
+#pragma unroll
+  for (int t = 0; t < TG; ++t) {
+    float* out = p.out + (size_t)blockIdx.z * p.k * p.k * p.Ci * p.Co + (size_t)(kh * p.k + t) * p.Ci * p.Co;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+      if (ci < p.Ci && co < p.Co) {
+        float* q = out + (size_t)ci * p.Co + co;
+        const float v = acc[t][r];
+        if (direct) *q = (p.beta != 0.f ? p.beta * *q : 0.f) + p.scale * v;
+        else *q = v;
+      }
+    }
+  }
+}
 
 // MODE 0: grid.y = tap; A = x rows shifted by the tap (float4 over ci), B = dy rows.
 // MODE 1: thin Ci (<= 4): the tap is folded into the M index, i = tap*Ci + ci (im2col columns gathered with
@@ -366,6 +768,14 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
     pl.tiles_n = 1;
     pl.taps_in_grid = 0;
   } else {
+  static const int no_tg = getenv("BG_WGRAD_NO_TG") ? 1 : 0;
+  if (k == 5 && Ci <= 64 && !no_tg) {
+    pl.bkp = 32; bm = 32;
+    if (Co > 32) { pl.mode = 6; bn = 64; } else { pl.mode = 7; bn = 32; }
+    pl.tiles_m = bg::cdiv(Ci, bm);
+    pl.tiles_n = bg::cdiv(Co, bn);
+    pl.taps_in_grid = 2;                       // grid.y = k (one kernel row of taps per workgroup)
+  } else {
   if (Ci > 64 && Co > 64) { pl.mode = 1; bm = 128; bn = 128; pl.bkp = 32; }
   else if (Ci > 32 && Co > 32) { pl.mode = 2; bm = 64; bn = 64; pl.bkp = 32; }
   else if (Ci > 32) { pl.mode = 3; bm = 64; bn = 32; pl.bkp = 64; }
@@ -375,7 +785,8 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
   pl.tiles_n = bg::cdiv(Co, bn);
   pl.taps_in_grid = 1;
   }
-  const long base = (long)pl.tiles_m * pl.tiles_n * (pl.taps_in_grid ? kk : 1);
+  }
+  const long base = (long)pl.tiles_m * pl.tiles_n * (pl.taps_in_grid == 1 ? kk : (pl.taps_in_grid == 2 ? k : 1));
   long want = std::max(1L, (768 + base - 1) / base);            // aim for ~3 workgroups per CU
   long steps = (M + pl.bkp - 1) / pl.bkp;
   want = std::min(want, std::max(1L, steps / 4));               // at least 4 K-steps per workgroup
@@ -415,8 +826,20 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
   bg::same_pads(H, ksize, stride, &p.Ho, &p.pt);
   bg::same_pads(W, ksize, stride, &p.Wo, &p.pl);
   p.M = B * p.Ho * p.Wo;
-  BG_REQUIRE((size_t)B * H * W * (size_t)Cin < (1ull << 31) && (size_t)p.M * (size_t)Cout < (1ull << 31), BG_ERR_UNSUPPORTED,
-             "bg_conv2d_bwd_filter: tensor exceeds 2^31 elements");
+  BG_REQUIRE((size_t)B * H * W * (size_t)Cin < (1ull << 29) && (size_t)p.M * (size_t)Cout < (1ull << 29), BG_ERR_UNSUPPORTED,
+             "bg_conv2d_bwd_filter: tensor exceeds 2 GiB");
+  {
+    auto magic = [](unsigned d, unsigned* mul, unsigned* sh) {
+      unsigned sft = 0;
+      while ((1ull << sft) < d) ++sft;
+      *mul = (unsigned)((1ull << (31 + sft)) / d + 1);
+      *sh = 31 + sft;
+    };
+    magic((unsigned)(p.Ho * p.Wo), &p.mul_hw, &p.sh_hw);
+    magic((unsigned)p.Wo, &p.mul_w, &p.sh_w);
+    p.x_bytes = (unsigned)((size_t)B * H * W * Cin * sizeof(float));
+    p.dy_bytes = (unsigned)((size_t)p.M * Cout * sizeof(float));
+  }
   p.chunk = pl.chunk; p.ksplit = pl.ksplit; p.tiles_n = pl.tiles_n;
   p.beta = beta; p.scale = scale;
   p.out = pl.ksplit > 1 ? static_cast<float*>(ws_d) : dw;
@@ -427,14 +850,16 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     hipLaunchKernelGGL(wgrad_direct_kernel, dim3(bg::cdiv(nout, 256), pl.ksplit), dim3(256), 0, L.s, p);
     rc = L.done("wgrad_direct_kernel");
   } else {
-    dim3 grid(pl.tiles_m * pl.tiles_n, pl.taps_in_grid ? ksize * ksize : 1, pl.ksplit);
+    dim3 grid(pl.tiles_m * pl.tiles_n, pl.taps_in_grid == 1 ? ksize * ksize : (pl.taps_in_grid == 2 ? ksize : 1), pl.ksplit);
     bg::Launch L(stream, pl.mode >= 20 ? "conv_wgrad_mfma_thin_co" : (pl.mode >= 10 ? "conv_wgrad_mfma_thin_ci" : "conv_wgrad_mfma"), flops, 0);
     switch (pl.mode) {
-      case 1: hipLaunchKernelGGL((conv_wgrad_kernel<128, 128, 32, 2, 2, 1, 0>), grid, dim3(256), 0, L.s, p); break;
-      case 2: hipLaunchKernelGGL((conv_wgrad_kernel<64, 64, 32, 2, 2, 1, 0>), grid, dim3(256), 0, L.s, p); break;
-      case 3: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64, 2, 1, 2, 0>), grid, dim3(256), 0, L.s, p); break;
-      case 4: hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 64, 1, 2, 2, 0>), grid, dim3(256), 0, L.s, p); break;
-      case 5: hipLaunchKernelGGL((conv_wgrad_kernel<32, 32, 128, 1, 1, 4, 0>), grid, dim3(256), 0, L.s, p); break;
+      case 1: hipLaunchKernelGGL((conv_wgrad_v3_kernel<128, 128, 32, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
+      case 2: hipLaunchKernelGGL((conv_wgrad_v3_kernel<64, 64, 32, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
+      case 3: hipLaunchKernelGGL((conv_wgrad_v3_kernel<64, 32, 64, 2, 1, 2>), grid, dim3(256), 0, L.s, p); break;
+      case 4: hipLaunchKernelGGL((conv_wgrad_v3_kernel<32, 64, 64, 1, 2, 2>), grid, dim3(256), 0, L.s, p); break;
+      case 5: hipLaunchKernelGGL((conv_wgrad_v3_kernel<32, 32, 128, 1, 1, 4>), grid, dim3(256), 0, L.s, p); break;
+      case 6: hipLaunchKernelGGL((conv_wgrad_tg_kernel<5, 64, 2, 2>), grid, dim3(256), 0, L.s, p); break;
+      case 7: hipLaunchKernelGGL((conv_wgrad_tg_kernel<5, 32, 1, 4>), grid, dim3(256), 0, L.s, p); break;
       case 10: hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 64, 1, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
       case 11: hipLaunchKernelGGL((conv_wgrad_kernel<96, 32, 64, 1, 1, 4, 1>), grid, dim3(256), 0, L.s, p); break;
       case 12: hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 64, 1, 1, 4, 1>), grid, dim3(256), 0, L.s, p); break;
