@@ -44,7 +44,12 @@ def init_from_env(backend=None):
 def all_reduce_sum_(flat):
     """In-place SUM all-reduce of a flat gradient buffer (no-op for a single replica)."""
     if world_size() > 1:
-        td.all_reduce(flat, op=td.ReduceOp.SUM)
+        if flat.is_cuda and td.get_backend() == "gloo":      # CPU test harness: stage through the host
+            host = flat.cpu()
+            td.all_reduce(host, op=td.ReduceOp.SUM)
+            flat.copy_(host)
+        else:
+            td.all_reduce(flat, op=td.ReduceOp.SUM)          # RCCL ring/tree over xGMI on the GPU box
     return flat
 
 

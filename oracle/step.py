@@ -89,6 +89,9 @@ def discriminator_grads(st, reals, rnd, hp):
     B = reals.shape[0]
     dt = reals.dtype.type
     inv_gbs = dt(1.0 / hp["global_batch_size"])
+    # data parallel (build-side definition): this call sees one shard of a global batch of
+    # B * dp_world samples; its gradients are meant to be SUMMED over the shards.
+    Bg = B * int(hp.get("dp_world", 1))
     fakes, _ = M.forward(st["gspec"], st["g"], rnd["z_d"], training=False)           # Q4
     fs, cf = critic_fwd(st, fakes, True, rnd["mask_fake"])
     rs, cr = critic_fwd(st, reals, True, rnd["mask_real"])
@@ -97,15 +100,16 @@ def discriminator_grads(st, reals, rnd, hp):
     gp_term = dt(hp["gp_coefficient"]) * gp
     norm_term = dt(hp["e_drift"]) * (np.abs(fs[:, 0]) + np.abs(rs[:, 0]))             # [B]
     disc_loss_vec = l_w + gp_term + norm_term                                           # Q1: [B]
-    # gradient of sum(disc_loss_vec): B*(l_w + gp_term) + sum(norm_term)
-    dfs = (B * inv_gbs + dt(hp["e_drift"]) * np.sign(fs)).astype(reals.dtype)
-    drs = (-B * inv_gbs + dt(hp["e_drift"]) * np.sign(rs)).astype(reals.dtype)
+    # gradient of sum(disc_loss_vec): B*(l_w + gp_term) + sum(norm_term)   (B = the global batch under DP)
+    dfs = (Bg * inv_gbs + dt(hp["e_drift"]) * np.sign(fs)).astype(reals.dtype)
+    drs = (-Bg * inv_gbs + dt(hp["e_drift"]) * np.sign(rs)).astype(reals.dtype)
     gf, _ = M.backward(st["dspec"], st["d"], cf, dfs, need_dx=False)
     gr, _ = M.backward(st["dspec"], st["d"], cr, drs, need_dx=False)
     grads = [dict() for _ in st["dspec"]]
     _acc(grads, gf)
     _acc(grads, gr)
-    _acc(grads, gp_grads, scale=dt(B * hp["gp_coefficient"]))
+    # gp_grads = d/dW mean_local((n-1)^2); global mean = (1/dp_world) * sum of local means, times the Q1 factor Bg
+    _acc(grads, gp_grads, scale=dt(Bg * hp["gp_coefficient"] / int(hp.get("dp_world", 1))))
     metrics = dict(fake_scores=float(fs.mean()), real_scores=float(rs.mean()),
                    disc_loss=float(disc_loss_vec.mean()), gp_term=float(gp_term),
                    norm_term=float(norm_term.mean()))

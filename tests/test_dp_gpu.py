@@ -1,0 +1,74 @@
+"""GPU check of the data-parallel path with 2 ranks sharing the one GPU of the test box (gloo rendezvous, gradients
+staged through the host): SUM of the ranks' critic gradients from the HIP step == the single-process HIP gradients
+at the global batch; both replicas end the step with identical weights."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _build(arch, B, gbs, seed=3):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    import blurred_gan_amd as bg
+    from blurred_gan_amd import models
+    from oracle import step as S
+    from helpers import load_oracle_weights
+    rng = np.random.default_rng(seed)
+    st = S.new_state(arch, rng, np.float64, std=0.8)
+    gen, disc = models.DCGANGenerator(arch=arch), models.DCGANDiscriminator(arch=arch)
+    hp = bg.BlurredWGANGP.HyperParameters(initial_blur_std=0.8, global_batch_size=gbs, batch_size=B)
+    gan = bg.BlurredWGANGP(gen, disc, hp, bg.TrainingConfig(log_dir="/tmp/bg_dp_logs"))
+    load_oracle_weights(gen, st["g"])
+    load_oracle_weights(disc, st["d"])
+    reals = rng.uniform(-1, 1, size=(gbs, 8, 8, 3)).astype(np.float32)
+    rnd = S.draw_randomness(arch, gbs, rng, np.float64)
+    return gan, reals, rnd
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from blurred_gan_amd import dist
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group(backend="gloo")
+    gan, reals, rnd = _build("tiny", 3, 6)
+    sh = lambda a: dist.shard(torch.from_numpy(np.asarray(a))).numpy()
+    rnd_local = {k: ([sh(m) for m in v] if isinstance(v, list) else sh(v)) for k, v in rnd.items()}
+    gan.train_on_batch(sh(reals), randomness=rnd_local)
+    st = gan.discriminator.store
+    np.save(os.path.join(out_dir, f"d_grad_{rank}.npy"), st.grad[:st.n_train].cpu().numpy())
+    np.save(os.path.join(out_dir, f"d_theta_{rank}.npy"), st.theta[:st.n_train].cpu().numpy())
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_two_ranks_match_single_process_global_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    gan, reals, rnd = _build("tiny", 6, 6)
+    gan.train_on_batch(reals, randomness=rnd)
+    st = gan.discriminator.store
+    ref_g, ref_t = st.grad[:st.n_train].cpu().numpy(), st.theta[:st.n_train].cpu().numpy()
+    g0, g1 = np.load(tmp_path / "d_grad_0.npy"), np.load(tmp_path / "d_grad_1.npy")
+    np.testing.assert_array_equal(g0, g1)                                   # all-reduced: identical on both ranks
+    np.testing.assert_allclose(g0, ref_g, rtol=2e-3, atol=2e-4 * np.abs(ref_g).max())
+    t0, t1 = np.load(tmp_path / "d_theta_0.npy"), np.load(tmp_path / "d_theta_1.npy")
+    np.testing.assert_array_equal(t0, t1)                                   # replicas stay in lock step
+    np.testing.assert_allclose(t0, ref_t, rtol=1e-3, atol=2e-4)
