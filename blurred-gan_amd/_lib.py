@@ -15,7 +15,7 @@ class BgError(RuntimeError):
 
 class Epilogue(C.Structure):
     _fields_ = [("mode", C.c_int), ("bias", C.c_void_p), ("ref", C.c_void_p), ("keep", C.c_void_p),
-                ("alpha", C.c_float), ("scale", C.c_float)]
+                ("alpha", C.c_float), ("scale", C.c_float), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t)]
 
 
 EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH = 0, 1, 2, 3
@@ -35,6 +35,7 @@ SIGNATURES = {
     "bg_gauss_kernel_1d": (_i, [_f, _f, C.POINTER(_f), _i, C.POINTER(_i)]),
     "bg_blur_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "bg_blur_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _p]),
+    "bg_conv2d_splitk_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "bg_conv2d_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
     "bg_conv2d_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
     "bg_conv2d_bwd_filter_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),

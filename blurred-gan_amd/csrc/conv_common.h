@@ -31,6 +31,8 @@ struct GatherParams {
   int ss, ds;          // source / destination stride multipliers
   unsigned a_bytes, w_bytes;   // operand sizes for the buffer descriptors of the MFMA kernel
   int nphase;
+  int ksplit;          // split-K factor of the MFMA kernel (1 = none); partial sums go to slab[split][B*Hd*Wd*N]
+  float* slab;
   // epilogue
   int epi_mode;
   const float* bias;

@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GatherParams p) {
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
   __shared__ int rowdst[BM];
 
-  const GatherPhase& g = p.ph[blockIdx.z];
+  const int phase = blockIdx.z % p.nphase, split = blockIdx.z / p.nphase;
+  const GatherPhase& g = p.ph[phase];
   const int Mph = p.B * g.Ha * g.Wa;
   const int m0 = blockIdx.x * BM;
   if (m0 >= Mph) return;
@@ -86,14 +87,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GatherParams p) {
   }
 
   const int kchunks = p.Ck / BK;
-  const int nsteps = g.ntaps * kchunks;
+  const int nsteps_all = g.ntaps * kchunks;
+  const int s_begin = (int)((long)nsteps_all * split / p.ksplit);          // this workgroup's slice of the K steps
+  const int nsteps = (int)((long)nsteps_all * (split + 1) / p.ksplit) - s_begin;
   float4 regA[AP], regB[BP];
 
   // Software pipeline (one barrier per step, loop body is a single basic block so the scheduler can slot the
   // loader's VALU / VMEM / DS-write work between MFMAs):
   //   step s:  MFMA(first half of tile s) | ds_write tile s+1 (its global loads were issued during step s-1)
   //            | issue global loads of tile s+2 | MFMA(second half of tile s) | barrier
-  auto gload = [&](int step) {
+  auto gload = [&](int lstep) {
+    const int step = s_begin + lstep;
     const int tq = step / kchunks;
     const int tp = g.tap[min(tq, g.ntaps - 1)];              // steps past the end re-load the last tap; never consumed
     const int c0 = (step - tq * kchunks) * BK;
@@ -186,7 +190,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const GatherParams p) {
         const int dst = rowdst[row];
         if (dst >= 0 && n < p.N) {
           const size_t idx = (size_t)dst * p.N + n;
-          p.C[idx] = bg::apply_epilogue(p, acc[i][j][r], idx, n);
+          if (p.ksplit > 1) p.slab[(size_t)split * ((size_t)p.B * p.Hd * p.Wd * p.N) + idx] = acc[i][j][r];
+          else p.C[idx] = bg::apply_epilogue(p, acc[i][j][r], idx, n);
         }
       }
     }
@@ -467,6 +472,15 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const GatherParams p) 
   p.C[idx] = bg::apply_epilogue(p, acc, idx, n);
 }
 
+// split-K tail: C = epilogue(sum over splits of the partial slabs)
+__global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const GatherParams p, size_t total) {
+  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int z = 0; z < p.ksplit; ++z) s += p.slab[(size_t)z * total + e];
+    p.C[e] = bg::apply_epilogue(p, s, e, (int)(e % p.N));
+  }
+}
+
 __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                               int R, int C) {
   __shared__ float tile[32][33];
@@ -496,17 +510,39 @@ double gather_flops(const GatherParams& p) {
   return f;
 }
 
+// split-K plan for small-M layers: fewer than 2 workgroups per CU and a long contraction
+int plan_splitk(const GatherParams& p, int bm, int bn, int bk) {
+  const long wgs = (long)bg::cdiv(max_phase_m(p), bm) * bg::cdiv(p.N, bn) * p.nphase;
+  int min_steps = 1 << 30;
+  for (int i = 0; i < p.nphase; ++i) min_steps = std::min(min_steps, p.ph[i].ntaps * (p.Ck / bk));
+  if (wgs >= 512 || min_steps < 32) return 1;
+  int ks = (int)std::min<long>(8, (768 + wgs - 1) / wgs);
+  ks = std::min(ks, min_steps / 16);
+  return std::max(ks, 1);
+}
+
 template <int BM, int BN, int BK, int WMv, int WNv>
-int launch_igemm(const GatherParams& p, void* stream, const char* name) {
+int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const char* name) {
   const int Mmax = max_phase_m(p);
-  dim3 grid(bg::cdiv(Mmax, BM), bg::cdiv(p.N, BN), p.nphase);
-  bg::Launch L(stream, name, gather_flops(p), 0);
-  hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv>), grid, dim3(256), 0, L.s, p);
-  return L.done(name);
+  const size_t total = (size_t)p.B * p.Hd * p.Wd * p.N;
+  int ks = plan_splitk(p, BM, BN, BK);
+  if (ks > 1 && !(epi && epi->splitk_ws && epi->splitk_ws_bytes >= ks * total * sizeof(float))) ks = 1;
+  p.ksplit = ks;
+  p.slab = ks > 1 ? static_cast<float*>(epi->splitk_ws) : nullptr;
+  dim3 grid(bg::cdiv(Mmax, BM), bg::cdiv(p.N, BN), p.nphase * ks);
+  {
+    bg::Launch L(stream, name, gather_flops(p), 0);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv>), grid, dim3(256), 0, L.s, p);
+    int rc = L.done(name);
+    if (rc || ks == 1) return rc;
+  }
+  bg::Launch L(stream, "conv_igemm_splitk_reduce", 0, (double)(ks + 1) * total * 4);
+  hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)std::min<size_t>(bg::cdiv(total, 256), 2048)), dim3(256), 0, L.s, p, total);
+  return L.done("igemm_splitk_reduce_kernel");
 }
 
 template <int BK>
-int dispatch_igemm(const GatherParams& p, void* stream, const char* tag) {
+int dispatch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const char* tag) {
   const int Mmax = max_phase_m(p);
   // Pick the tile that keeps >= 2 workgroups per CU resident (two waves per SIMD: one issues MFMAs while the
   // other runs its loader segment); bigger tiles only when the grid still fills the chip twice over.
@@ -520,15 +556,16 @@ int dispatch_igemm(const GatherParams& p, void* stream, const char* tag) {
   else pick = 4;
   if (pick == 3 && p.N > 32) pick = 2;
   switch (pick) {
-    case 1: return launch_igemm<128, 128, BK, 2, 2>(p, stream, tag);
-    case 2: return launch_igemm<128, 64, BK, 2, 2>(p, stream, tag);
-    case 3: return launch_igemm<128, 32, BK, 4, 1>(p, stream, tag);
-    default: return launch_igemm<64, 64, BK, 2, 2>(p, stream, tag);
+    case 1: return launch_igemm<128, 128, BK, 2, 2>(p, epi, stream, tag);
+    case 2: return launch_igemm<128, 64, BK, 2, 2>(p, epi, stream, tag);
+    case 3: return launch_igemm<128, 32, BK, 4, 1>(p, epi, stream, tag);
+    default: return launch_igemm<64, 64, BK, 2, 2>(p, epi, stream, tag);
   }
 }
 
 int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char* tag) {
   p.epi_mode = BG_EPI_NONE; p.bias = nullptr; p.ref = nullptr; p.keep = nullptr; p.alpha = 0.3f; p.scale = 1.f;
+  p.ksplit = 1; p.slab = nullptr;
   if (epi) {
     p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep;
     p.alpha = epi->alpha; p.scale = epi->scale;
@@ -549,7 +586,7 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     p.w_bytes = (unsigned)w_bytes;
     snprintf(name, sizeof name, "conv_igemm_%s", tag);
     static const int force_bk = getenv("BG_IGEMM_BK") ? atoi(getenv("BG_IGEMM_BK")) : 0;   // tuning aid
-    return (p.Ck % 32 == 0 && force_bk != 16) ? dispatch_igemm<32>(p, stream, name) : dispatch_igemm<16>(p, stream, name);
+    return (p.Ck % 32 == 0 && force_bk != 16) ? dispatch_igemm<32>(p, epi, stream, name) : dispatch_igemm<16>(p, epi, stream, name);
   }
   if (p.N <= 4 && (p.Ck == 16 || p.Ck == 32 || p.Ck == 64)) {
     // LDS patch kernel: patch = anchor tile + tap halo of the widest phase
@@ -639,6 +676,18 @@ int check_conv_args(const char* fn, const void* a, const void* w, const void* c,
 }  // namespace
 
 extern "C" {
+
+size_t bg_conv2d_splitk_workspace_bytes(int bwd_data, int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize < 1 || !(ksize & 1) || ksize * ksize > bg::kMaxTaps || (stride != 1 && stride != 2)) return 0;
+  GatherParams p;
+  memset(&p, 0, sizeof p);
+  if (bwd_data) bg::make_bwd_data_params(p, B, H, W, Cin, Cout, ksize, stride);
+  else bg::make_fwd_params(p, B, H, W, Cin, Cout, ksize, stride);
+  if (p.Ck % 16 != 0 || p.N <= 4) return 0;
+  const int bk = p.Ck % 32 == 0 ? 32 : 16;
+  const int ks = p.N <= 32 ? plan_splitk(p, 128, 32, bk) : plan_splitk(p, 64, 64, bk);
+  return ks > 1 ? (size_t)ks * p.B * p.Hd * p.Wd * p.N * sizeof(float) : 0;
+}
 
 int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int W, int Cin, int Cout, int ksize,
                   int stride, const bg_epilogue* epi, void* stream) {

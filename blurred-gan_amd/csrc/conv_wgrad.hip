@@ -698,19 +698,29 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const WgradParams p) 
   else *q = acc;
 }
 
+// dw = beta*dw + scale * sum_z slabs[z]; block = 64 float4 columns x 4 slab groups (LDS tree), so few-output layers
+// with many slabs still expose enough parallelism
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int n,
                                                            int ksplit, float beta, float scale) {
-  const int e = (blockIdx.x * 256 + threadIdx.x) * 4;     // n is a multiple of 4 on this path, slabs 16-B aligned
-  if (e >= n) return;
+  __shared__ float4 red[4][64];
+  const int lane = threadIdx.x & 63, zg = threadIdx.x >> 6;
+  const int e = (blockIdx.x * 64 + lane) * 4;             // n is a multiple of 4 on this path, slabs 16-B aligned
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-  for (int z = 0; z < ksplit; ++z) {
-    const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + e);
-    s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+  if (e < n) {
+    for (int z = zg; z < ksplit; z += 4) {
+      const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
   }
-  float4 o = make_float4(scale * s.x, scale * s.y, scale * s.z, scale * s.w);
+  red[zg][lane] = s;
+  __syncthreads();
+  if (zg != 0 || e >= n) return;
+  const float4 a = red[0][lane], b = red[1][lane], c = red[2][lane], d = red[3][lane];
+  float4 o = make_float4(scale * ((a.x + b.x) + (c.x + d.x)), scale * ((a.y + b.y) + (c.y + d.y)),
+                         scale * ((a.z + b.z) + (c.z + d.z)), scale * ((a.w + b.w) + (c.w + d.w)));
   if (beta != 0.f) {
-    const float4 d = *reinterpret_cast<const float4*>(dw + e);
-    o.x += beta * d.x; o.y += beta * d.y; o.z += beta * d.z; o.w += beta * d.w;
+    const float4 q = *reinterpret_cast<const float4*>(dw + e);
+    o.x += beta * q.x; o.y += beta * q.y; o.z += beta * q.z; o.w += beta * q.w;
   }
   *reinterpret_cast<float4*>(dw + e) = o;
 }
@@ -769,7 +779,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
     pl.taps_in_grid = 0;
   } else {
   static const int no_tg = getenv("BG_WGRAD_NO_TG") ? 1 : 0;
-  if (k == 5 && Ci <= 64 && !no_tg) {
+  if (k == 5 && Ci <= 64 && !no_tg && M >= 131072) {
     pl.bkp = 32; bm = 32;
     if (Co > 32) { pl.mode = 6; bn = 64; } else { pl.mode = 7; bn = 32; }
     pl.tiles_m = bg::cdiv(Ci, bm);
@@ -873,7 +883,7 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
   if (pl.ksplit > 1) {
     bg::Launch L(stream, "conv_wgrad_reduce", 0, (double)(pl.ksplit + 1) * nout * 4);
     if (nout % 4 == 0 && bg::aligned16(ws_d))
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bg::cdiv(nout / 4, 256)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bg::cdiv(nout / 4, 64)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,
                          (int)nout, pl.ksplit, beta, scale);
     else
       hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(bg::cdiv(nout, 256)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,

@@ -111,6 +111,7 @@ class Net:
         self._ctx = {}
         self._ws = None
         self._taps_cache = {}
+        self._splitk_bytes = {}
         self.rng_offset = 0
 
     # ------------------------------------------------------------------ resources
@@ -125,6 +126,14 @@ class Net:
         if self._ws is None or self._ws.numel() * 4 < n:
             self._ws = torch.empty((n + 3) // 4 + 1024, dtype=torch.float32, device=self.device)
         return self._ws
+
+    def _epi(self, bwd_data, B, H, W, Cin, Cout, k, stride, mode, **kw):
+        """Epilogue descriptor for one conv launch; attaches split-K scratch when the library's plan wants it."""
+        key = (bool(bwd_data), B, H, W, Cin, Cout, k, stride)
+        nb = self._splitk_bytes.get(key)
+        if nb is None:
+            nb = self._splitk_bytes[key] = ops.conv2d_splitk_workspace_bytes(bwd_data, B, H, W, Cin, Cout, k, stride)
+        return ops.epilogue(mode, ws=self.workspace(nb) if nb else None, **kw)
 
     def prepare_weights(self):
         """(Re)builds the transposed kernel copies the 'other direction' of each conv needs."""
@@ -200,15 +209,20 @@ class Net:
                 K, N = st.in_shape[0], st.out_shape[0]
                 ops.gemm(xin, st.lin.vars["kernel"], tgt, B, N, K, bias=bias)
             else:
+                lin = st.lin
+                if st.kind == "conv":
+                    geom = (False, B, st.in_shape[0], st.in_shape[1], st.in_shape[2], lin.filters, lin.k, lin.stride)
+                else:           # ConvT forward == data-gradient of the conv whose input side is this layer's output
+                    geom = (True, B, st.out_shape[0], st.out_shape[1], lin.filters, st.in_shape[2], lin.k, lin.stride)
                 if st.bn is not None:
-                    epi = ops.epilogue(EPI_NONE, bias=bias)
+                    epi = self._epi(*geom, EPI_NONE, bias=bias)
                 elif st.act == "lrelu":
-                    epi = ops.epilogue(EPI_BIAS_LRELU, bias=bias, keep=keep, alpha=st.alpha,
-                                       scale=1.0 / (1.0 - st.drop) if st.drop else 1.0)
+                    epi = self._epi(*geom, EPI_BIAS_LRELU, bias=bias, keep=keep, alpha=st.alpha,
+                                    scale=1.0 / (1.0 - st.drop) if st.drop else 1.0)
                 elif st.act == "tanh":
-                    epi = ops.epilogue(EPI_TANH, bias=bias)
+                    epi = self._epi(*geom, EPI_TANH, bias=bias)
                 else:
-                    epi = ops.epilogue(EPI_NONE, bias=bias)
+                    epi = self._epi(*geom, EPI_NONE, bias=bias)
                 if st.kind == "conv":
                     ops.conv2d_fwd(xin, self.store.transposed_kernel(st.lin), tgt, st.lin.k, st.lin.stride, epi)
                 else:   # Conv2DTranspose forward == data-gradient of the conv with the same kernel array
@@ -298,10 +312,17 @@ class Net:
             fuse = prev is not None and prev.fusable_grad and st.kind != "dense"
             tgt = ctx.buf(ctx.dz, i - 1).view(B, *st.in_shape) if i > 0 else ctx.input_grad().view(B, *st.in_shape)
             epi = None
-            if fuse:
-                pk = ctx.keep[i - 1] if (prev.drop and ctx.dropout_active) else None
-                epi = ops.epilogue(EPI_MUL_GRAD, ref=ctx.a[i - 1], keep=pk, alpha=prev.alpha,
-                                   scale=1.0 / (1.0 - prev.drop) if pk is not None else 1.0)
+            if st.kind != "dense":
+                if st.kind == "conv":
+                    geom = (True, B, st.in_shape[0], st.in_shape[1], st.in_shape[2], lin.filters, lin.k, lin.stride)
+                else:
+                    geom = (False, B, st.out_shape[0], st.out_shape[1], lin.filters, st.in_shape[2], lin.k, lin.stride)
+                if fuse:
+                    pk = ctx.keep[i - 1] if (prev.drop and ctx.dropout_active) else None
+                    epi = self._epi(*geom, EPI_MUL_GRAD, ref=ctx.a[i - 1], keep=pk, alpha=prev.alpha,
+                                    scale=1.0 / (1.0 - prev.drop) if pk is not None else 1.0)
+                else:
+                    epi = self._epi(*geom, EPI_NONE)
             if st.kind == "dense":
                 K, N = st.in_shape[0], st.out_shape[0]
                 ops.gemm(dz, lin.vars["kernel"], tgt, B, K, N, transB=True)
@@ -335,7 +356,7 @@ class Net:
                 ops.conv2d_bwd_filter(vin, ctx.dz[i], st_.grad_of(lin, "kernel"), lin.k, lin.stride, 1.0, 1.0,
                                       self.workspace(nb) if nb else None)
                 vo = ctx.buf(ctx.v, i)
-                epi = ops.epilogue(EPI_MUL_GRAD, ref=ctx.a[i], alpha=st.alpha)
+                epi = self._epi(False, Bc, H, W, Ci, lin.filters, lin.k, lin.stride, EPI_MUL_GRAD, ref=ctx.a[i], alpha=st.alpha)
                 ops.conv2d_fwd(vin, self.store.transposed_kernel(lin), vo, lin.k, lin.stride, epi)
                 v = vo
             elif st.kind == "dense" and last and st.out_shape == (1,) and st.bn is None and st.act is None:

@@ -41,14 +41,20 @@ def same_out(n, s):
     return -(-n // s)
 
 
-def epilogue(mode=EPI_NONE, bias=None, ref=None, keep=None, alpha=LRELU_ALPHA, scale=1.0):
+def conv2d_splitk_workspace_bytes(bwd_data, B, H, W, Cin, Cout, ksize, stride):
+    return _lib.load().bg_conv2d_splitk_workspace_bytes(int(bwd_data), B, H, W, Cin, Cout, ksize, stride)
+
+
+def epilogue(mode=EPI_NONE, bias=None, ref=None, keep=None, alpha=LRELU_ALPHA, scale=1.0, ws=None):
     e = Epilogue()
+    e.splitk_ws = ws.data_ptr() if ws is not None else None
+    e.splitk_ws_bytes = ws.numel() * ws.element_size() if ws is not None else 0
     e.mode = mode
     e.bias = bias.data_ptr() if bias is not None else None
     e.ref = ref.data_ptr() if ref is not None else None
     e.keep = keep.data_ptr() if keep is not None else None
     e.alpha, e.scale = alpha, scale
-    e._hold = (bias, ref, keep)      # keep the tensors alive for the duration of the launch call
+    e._hold = (bias, ref, keep, ws)  # keep the tensors alive for the duration of the launch call
     return e
 
 

@@ -91,8 +91,12 @@ typedef struct {
   const uint8_t* keep;    /* dropout keep mask (1 = kept), same shape as y, or NULL             */
   float alpha;            /* LeakyReLU slope (Keras default 0.3)                                */
   float scale;            /* 1 / keep_prob                                                      */
+  void* splitk_ws;        /* optional scratch for split-K partial sums (small-M layers); NULL = never split */
+  size_t splitk_ws_bytes; /* >= bg_conv2d_splitk_workspace_bytes(...) for the call to use split-K      */
 } bg_epilogue;
 
+/* bytes of split-K scratch the forward (bwd_data = 0) / data-gradient (bwd_data = 1) call can use; 0 = never splits */
+size_t bg_conv2d_splitk_workspace_bytes(int bwd_data, int B, int H, int W, int Cin, int Cout, int ksize, int stride);
 /* y[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w) ; wT_d = [k*k][Cout][Cin] */
 int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int W, int Cin, int Cout,
                   int ksize, int stride, const bg_epilogue* epi, void* stream);
