@@ -85,7 +85,102 @@ __global__ __launch_bounds__(kFusedThreads) void blur_fused_kernel(const float* 
   }
 }
 
-// AXIS 0: along H (neighbour stride W*C); AXIS 1: along W (neighbour stride C).
+// Images larger than LDS: two passes through a scratch image in HBM (traffic 2x algorithmic), each pass holding
+// whole lines along the filtered axis in LDS so no halo is ever re-read, same register sliding window.
+//   pass H: workgroup = one image x a strip of kStripW consecutive (w,c) columns, all H rows resident
+//   pass W: workgroup = kRowsW full rows of one image
+constexpr int kStripW = 64, kLineThreads = 256;
+
+__global__ __launch_bounds__(kLineThreads) void blur_lines_h_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                    int H, int WC, int strips,
+                                                                    const float* __restrict__ taps, int T) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int half = T >> 1;
+  float* s0 = lds;                         // [H][kStripW]
+  float* tp = lds + H * kStripW;           // taps + kR zeros
+  const int img = blockIdx.x / strips, strip = blockIdx.x - img * strips;
+  const int c0 = strip * kStripW;
+  const int cw = min(kStripW, WC - c0);
+  const float* xi = x + (size_t)img * H * WC + c0;
+  float* yi = y + (size_t)img * H * WC + c0;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < T + kR; j += kLineThreads) tp[j] = j < T ? taps[j] : 0.f;
+  for (int e = tid; e < H * kStripW; e += kLineThreads) {
+    const int h = e / kStripW, c = e - h * kStripW;
+    s0[e] = c < cw ? xi[(size_t)h * WC + c] : 0.f;
+  }
+  __syncthreads();
+  const int HQ = (H + kR - 1) / kR;
+  for (int item = tid; item < kStripW * HQ; item += kLineThreads) {
+    const int hq = item / kStripW, c = item - hq * kStripW;
+    if (c >= cw) continue;
+    const int h0 = hq * kR;
+    float acc[kR], tw[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) { acc[r] = 0.f; tw[r] = 0.f; }
+    // only source rows inside the image contribute: clip the sweep to them (large T, small H)
+    const int jlo = max(0, half - h0 - (kR - 1)), jhi = min(T + kR - 1, H + half - h0);
+#pragma unroll
+    for (int q = 0; q < kR - 1; ++q) tw[q] = (jlo - 1 - q >= 0) ? tp[jlo - 1 - q] : 0.f;   // tap history for the first sample
+    for (int j = jlo; j < jhi; ++j) {
+#pragma unroll
+      for (int r = kR - 1; r > 0; --r) tw[r] = tw[r - 1];
+      tw[0] = tp[j];
+      const int srow = h0 - half + j;
+      const float v = (unsigned)srow < (unsigned)H ? s0[srow * kStripW + c] : 0.f;
+#pragma unroll
+      for (int r = 0; r < kR; ++r) acc[r] = fmaf(tw[r], v, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < kR; ++r)
+      if (h0 + r < H) yi[(size_t)(h0 + r) * WC + c] = acc[r];
+  }
+}
+
+__global__ __launch_bounds__(kLineThreads) void blur_lines_w_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                    int rows_total, int W, int C, int rows_per,
+                                                                    const float* __restrict__ taps, int T) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int half = T >> 1, WC = W * C;
+  float* s1 = lds;                         // [rows_per][WC]
+  float* tp = lds + rows_per * WC;
+  const int r0 = blockIdx.x * rows_per;
+  const int nr = min(rows_per, rows_total - r0);
+  const float* xi = x + (size_t)r0 * WC;
+  float* yi = y + (size_t)r0 * WC;
+  const int tid = threadIdx.x;
+  for (int j = tid; j < T + kR; j += kLineThreads) tp[j] = j < T ? taps[j] : 0.f;
+  for (int e = tid; e < nr * WC; e += kLineThreads) s1[e] = xi[e];
+  __syncthreads();
+  const int WQ = (W + kR - 1) / kR;
+  for (int item = tid; item < nr * WQ * C; item += kLineThreads) {
+    const int c = item % C;
+    const int t2 = item / C;
+    const int wq = t2 % WQ, h = t2 / WQ;
+    const int w0 = wq * kR;
+    const float* row = s1 + h * WC + c;
+    float acc[kR], tw[kR];
+#pragma unroll
+    for (int r = 0; r < kR; ++r) { acc[r] = 0.f; tw[r] = 0.f; }
+    const int jlo = max(0, half - w0 - (kR - 1)), jhi = min(T + kR - 1, W + half - w0);
+#pragma unroll
+    for (int q = 0; q < kR - 1; ++q) tw[q] = (jlo - 1 - q >= 0) ? tp[jlo - 1 - q] : 0.f;
+    for (int j = jlo; j < jhi; ++j) {
+#pragma unroll
+      for (int r = kR - 1; r > 0; --r) tw[r] = tw[r - 1];
+      tw[0] = tp[j];
+      const int scol = w0 - half + j;
+      const float v = (unsigned)scol < (unsigned)W ? row[scol * C] : 0.f;
+#pragma unroll
+      for (int r = 0; r < kR; ++r) acc[r] = fmaf(tw[r], v, acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < kR; ++r)
+      if (w0 + r < W) yi[(size_t)(h * W + w0 + r) * C + c] = acc[r];
+  }
+}
+
+// last-resort generic pass (lines that do not fit LDS): one thread per output through L1/L2
 template <int AXIS>
 __global__ __launch_bounds__(kBlurThreads) void blur_pass_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                  size_t total, int H, int W, int C,
@@ -178,6 +273,30 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   }
   BG_REQUIRE(tmp_d != nullptr, BG_ERR_WORKSPACE, "bg_blur_nhwc_f32: image of %zu bytes needs tmp_d (see bg_blur_workspace_bytes)",
              (size_t)H * W * C * 4);
+  const int WC = W * C;
+  const size_t lds_h = ((size_t)H * kStripW + n_taps + kR + 4) * sizeof(float);
+  int rows_per = (int)std::min<size_t>(8, std::max<size_t>(1, (48 * 1024 / sizeof(float)) / (size_t)WC));
+  const size_t lds_w = ((size_t)rows_per * WC + n_taps + kR + 4) * sizeof(float);
+  if (lds_h <= 140 * 1024 && lds_w <= 140 * 1024) {
+    static bool attr_set2 = false;
+    if (!attr_set2) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur_lines_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur_lines_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
+      attr_set2 = true;
+    }
+    const int strips = (int)bg::cdiv(WC, kStripW);
+    {
+      bg::Launch L(stream, "blur_lines_h", flops / 2, bytes);
+      hipLaunchKernelGGL(blur_lines_h_kernel, dim3((unsigned)B * strips), dim3(kLineThreads), lds_h, s, x, tmp_d, H, WC, strips, taps_d, n_taps);
+      int rc = L.done("blur_lines_h_kernel");
+      if (rc) return rc;
+    }
+    const int rows_total = B * H;
+    bg::Launch L(stream, "blur_lines_w", flops / 2, bytes);
+    hipLaunchKernelGGL(blur_lines_w_kernel, dim3(bg::cdiv(rows_total, rows_per)), dim3(kLineThreads), lds_w, s, tmp_d, y, rows_total, W, C,
+                       rows_per, taps_d, n_taps);
+    return L.done("blur_lines_w_kernel");
+  }
   const unsigned grid = (unsigned)std::min<size_t>(bg::cdiv(total, kBlurThreads), 256 * 16);
   {
     bg::Launch L(stream, "blur_pass_h", flops / 2, bytes);
