@@ -28,12 +28,13 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // MFMA implicit GEMM
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(const GatherParams p) {
-  static_assert(WAVES_M * WAVES_N == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(const GatherParams p) {
+  constexpr int NT = WAVES_M * WAVES_N * 64;     // 4 or 8 waves per workgroup
+  static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
   static_assert(BK == 16 || BK == 32, "BK");
   constexpr int LD = BK + 4;                  // row stride (floats): 16-B aligned, conflict-free b128 reads
   constexpr int TPR = BK / 4;                 // loader threads per row (one float4 each)
-  constexpr int RPP = 256 / TPR;              // rows per loader pass
+  constexpr int RPP = NT / TPR;               // rows per loader pass
   constexpr int AP = (BM + RPP - 1) / RPP;    // loader passes for A
   constexpr int BP = (BN + RPP - 1) / RPP;    // loader passes for B
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -266,6 +267,84 @@ __global__ __launch_bounds__(256) void conv_thin_n_patch_kernel(const GatherPara
         const size_t idx = dst * N + n;
         p.C[idx] = bg::apply_epilogue(p, acc[n], idx, n);
       }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// thin-N forward on MFMA (stride 1, N*k <= 16; the generator's last conv 32->3 / 16->3):
+// the channel contraction runs on v_mfma_f32_16x16x4_f32 with the (kw, n) pairs as the 16 MFMA columns,
+//   P[x'][kw*N + n] = sum_{kh, c} in[oy + kh - pt][x'][c] * w[kh][kw][n][c]        (x' = input column)
+// and the kw shift is a 5-term add afterwards:  y[oy][ox][n] = sum_kw P[ox + kw - pl][kw*N + n].
+// One wave per output row of a 64-column tile, 5 M-tiles of 16 input columns, channels staged in chunks of 16
+// (pixel stride 17 floats -> conflict-free b32 fragment reads).
+// ------------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int kTnRows = 4, kTnCols = 64, kTnPx = 80, kTnCc = 16, kTnCS = kTnCc + 1;
+
+__global__ __launch_bounds__(256) void conv_thin_n_mfma_kernel(const GatherParams p, int k, int pt, int pl) {
+  extern __shared__ __attribute__((aligned(16))) float tn_lds[];
+  const int b = blockIdx.z, oy0 = blockIdx.y * kTnRows, ox0 = blockIdx.x * kTnCols;
+  const int N = p.N, Ck = p.Ck, prow = kTnRows + k - 1;
+  float* patch = tn_lds;                                   // [prow][kTnPx][kTnCS]
+  float* Ws = patch + prow * kTnPx * kTnCS;                // [k][kTnCc][16]
+  float* Pb = Ws + k * kTnCc * 16;                         // [4 waves][kTnPx][17]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* src = p.A + (size_t)b * p.Hs * p.Ws * Ck;
+  floatx4 acc[5];
+#pragma unroll
+  for (int t = 0; t < 5; ++t) acc[t] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int frow = lane & 15, fk = lane >> 4;
+  for (int c0 = 0; c0 < Ck; c0 += kTnCc) {
+    __syncthreads();                                        // previous chunk fully consumed
+    // patch chunk: input rows oy0-pt .., columns ox0-pl .. (zero outside the image / past the tile)
+    for (int idx = tid; idx < prow * kTnPx * (kTnCc / 4); idx += 256) {
+      const int q = idx % (kTnCc / 4), pix = idx / (kTnCc / 4);
+      const int py = pix / kTnPx, px = pix - py * kTnPx;
+      const int sy = oy0 - pt + py, sx = ox0 - pl + px;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws && c0 + q * 4 < Ck)
+        v = *reinterpret_cast<const float4*>(src + ((size_t)sy * p.Ws + sx) * Ck + c0 + q * 4);
+      float* d = patch + pix * kTnCS + q * 4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    // weights chunk: Ws[kh][c][kw*N + n] = Wt[kh*k + kw][n][c0 + c]
+    for (int idx = tid; idx < k * kTnCc * 16; idx += 256) {
+      const int j = idx & 15, c = (idx >> 4) % kTnCc, kh = idx / (16 * kTnCc);
+      const int kw = j / N, n = j - kw * N;
+      float v = 0.f;
+      if (kw < k && c0 + c < Ck) v = p.Wt[((size_t)(kh * k + kw) * N + n) * Ck + c0 + c];
+      Ws[idx] = v;
+    }
+    __syncthreads();
+    const float* prow0 = patch + (wave * kTnPx + frow) * kTnCS + fk;     // this wave's output row, kh = 0
+    for (int kh = 0; kh < k; ++kh) {
+      const float* pa = prow0 + kh * kTnPx * kTnCS;
+      const float* pw = Ws + (kh * kTnCc + fk) * 16 + frow;
+#pragma unroll
+      for (int ks = 0; ks < kTnCc / 4; ++ks) {
+        const float bv = pw[ks * 4 * 16];
+#pragma unroll
+        for (int t = 0; t < 5; ++t)
+          acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[t * 16 * kTnCS + ks * 4], bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  // P tile -> LDS: reg r of lane l holds P[x' = t*16 + 4*(l>>4) + r][col = l&15]
+  float* P = Pb + wave * kTnPx * 17;
+#pragma unroll
+  for (int t = 0; t < 5; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) P[(t * 16 + 4 * fk + r) * 17 + frow] = acc[t][r];
+  __syncthreads();
+  const int oy = oy0 + wave, ox = ox0 + lane;
+  if (oy < p.Hd && ox < p.Wd) {
+    const size_t dst = ((size_t)b * p.Hd + oy) * p.Wd + ox;
+    for (int n = 0; n < N; ++n) {
+      float v = 0.f;
+      for (int kw = 0; kw < k; ++kw) v += P[(lane + kw) * 17 + kw * N + n];
+      const size_t idx = dst * N + n;
+      p.C[idx] = bg::apply_epilogue(p, v, idx, n);
+    }
   }
 }
 
@@ -532,7 +611,7 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
   dim3 grid(bg::cdiv(Mmax, BM), bg::cdiv(p.N, BN), p.nphase * ks);
   {
     bg::Launch L(stream, name, gather_flops(p), 0);
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv>), grid, dim3(256), 0, L.s, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
     int rc = L.done(name);
     if (rc || ks == 1) return rc;
   }
@@ -557,6 +636,8 @@ int dispatch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const 
   if (pick == 3 && p.N > 32) pick = 2;
   switch (pick) {
     case 1: return launch_igemm<128, 128, BK, 2, 2>(p, epi, stream, tag);
+    case 5: return launch_igemm<128, 128, BK, 2, 4>(p, epi, stream, tag);    // 8 waves, 64x32 per wave
+    case 6: return launch_igemm<128, 64, BK, 4, 2>(p, epi, stream, tag);     // 8 waves, 32x32 per wave
     case 2: return launch_igemm<128, 64, BK, 2, 2>(p, epi, stream, tag);
     case 3: return launch_igemm<128, 32, BK, 4, 1>(p, epi, stream, tag);
     default: return launch_igemm<64, 64, BK, 2, 2>(p, epi, stream, tag);
@@ -587,6 +668,28 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     snprintf(name, sizeof name, "conv_igemm_%s", tag);
     static const int force_bk = getenv("BG_IGEMM_BK") ? atoi(getenv("BG_IGEMM_BK")) : 0;   // tuning aid
     return (p.Ck % 32 == 0 && force_bk != 16) ? dispatch_igemm<32>(p, epi, stream, name) : dispatch_igemm<16>(p, epi, stream, name);
+  }
+  if (p.nphase == 1 && p.ss == 1 && p.ds == 1 && p.Ck % 4 == 0 && p.Ck >= 16 && p.B <= 65535) {
+    // full k x k tap rectangle of a stride-1 forward conv with N*k <= 16 -> MFMA thin-N kernel
+    int k = 1;
+    while (k * k < p.ph[0].ntaps) ++k;
+    const int pt = -bg::tap_dy(p.ph[0].tap[0]), pl = -bg::tap_dx(p.ph[0].tap[0]);
+    bool rect = k * k == p.ph[0].ntaps && k <= 5 && p.N * k <= 16;
+    for (int t = 0; rect && t < p.ph[0].ntaps; ++t)
+      rect = bg::tap_dy(p.ph[0].tap[t]) == t / k - pt && bg::tap_dx(p.ph[0].tap[t]) == t % k - pl && bg::tap_wi(p.ph[0].tap[t]) == t;
+    static const int no_tn = getenv("BG_NO_THIN_N_MFMA") ? 1 : 0;
+    if (rect && pl + kTnCols + (k - 1 - pl) <= kTnPx && !no_tn) {
+      const size_t lds = ((size_t)(kTnRows + k - 1) * kTnPx * kTnCS + (size_t)k * kTnCc * 16 + 4 * kTnPx * 17) * sizeof(float);
+      static bool attr_tn = false;
+      if (!attr_tn) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_n_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
+        attr_tn = true;
+      }
+      snprintf(name, sizeof name, "conv_thin_n_mfma_%s", tag);
+      bg::Launch L(stream, name, gather_flops(p), 0);
+      hipLaunchKernelGGL(conv_thin_n_mfma_kernel, dim3(bg::cdiv(p.Wd, kTnCols), bg::cdiv(p.Hd, kTnRows), p.B), dim3(256), lds, L.s, p, k, pt, pl);
+      return L.done(name);
+    }
   }
   if (p.N <= 4 && (p.Ck == 16 || p.Ck == 32 || p.Ck == 64)) {
     // LDS patch kernel: patch = anchor tile + tap halo of the widest phase
