@@ -17,6 +17,7 @@ SOURCES = ["runtime.hip", "blur.hip", "conv_igemm.hip", "conv_wgrad.hip", "misc.
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]   # fp contraction off: fmaf() is explicit where wanted
+FLAGS += os.environ.get("BG_EXTRA_FLAGS", "").split()
 
 
 def _newer(a, b):

@@ -31,6 +31,7 @@ struct GatherParams {
   int ss, ds;          // source / destination stride multipliers
   unsigned a_bytes, w_bytes;   // operand sizes for the buffer descriptors of the MFMA kernel
   int nphase;
+  int mtiles, xcd_swizzle;   // MFMA kernel: M tiles per phase, XCD-aware tile order on/off
   int ksplit;          // split-K factor of the MFMA kernel (1 = none); partial sums go to slab[split][B*Hd*Wd*N]
   float* slab;
   // epilogue
@@ -96,6 +97,15 @@ inline int make_bwd_data_params(GatherParams& p, int B, int H, int W, int Cin, i
 }
 
 // device helpers -------------------------------------------------------------------------------
+// XCD-aware work order: hardware deals workgroups round-robin over the 8 XCDs (each with a private 4 MiB L2), so
+// blocks b and b+8 share an L2.  This bijection hands every XCD one contiguous run of the logical work list, so
+// neighbours in that list (which share an operand panel) meet in the same L2.  Speed only, never correctness.
+__device__ inline int xcd_remap(int bid, int nwg) {
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int q = nwg >> 3, r = nwg & 7;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+}
+
 struct RowAnchor {
   int b, ay, ax;  // image index, anchor*ss (source-space origin); ay = INT_MIN/2 marks an invalid row
 };

@@ -50,9 +50,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   const int phase = blockIdx.z % p.nphase, split = blockIdx.z / p.nphase;
   const GatherPhase& g = p.ph[phase];
   const int Mph = p.B * g.Ha * g.Wa;
-  const int m0 = blockIdx.x * BM;
+  // logical tile list is n-major (all M tiles of one weight panel, then the next panel): with the XCD remap each
+  // XCD's L2 holds only its share of the weight panels while the activations stream through
+  const int mt = p.mtiles;
+  const int L = p.xcd_swizzle ? bg::xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int n_tile = L / mt, m_tile = L - n_tile * mt;
+  const int m0 = m_tile * BM;
   if (m0 >= Mph) return;
-  const int n0 = blockIdx.y * BN;
+  const int n0 = n_tile * BN;
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -608,7 +613,10 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
   if (ks > 1 && !(epi && epi->splitk_ws && epi->splitk_ws_bytes >= ks * total * sizeof(float))) ks = 1;
   p.ksplit = ks;
   p.slab = ks > 1 ? static_cast<float*>(epi->splitk_ws) : nullptr;
-  dim3 grid(bg::cdiv(Mmax, BM), bg::cdiv(p.N, BN), p.nphase * ks);
+  p.mtiles = (int)bg::cdiv(Mmax, BM);
+  static const int no_swz = getenv("BG_NO_XCD_SWIZZLE") ? 1 : 0;
+  p.xcd_swizzle = !no_swz;
+  dim3 grid(p.mtiles * bg::cdiv(p.N, BN), 1, p.nphase * ks);
   {
     bg::Launch L(stream, name, gather_flops(p), 0);
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv>), grid, dim3(WMv * WNv * 64), 0, L.s, p);

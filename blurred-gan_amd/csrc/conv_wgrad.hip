@@ -24,7 +24,7 @@ struct WgradParams {
   int M;             // B*Ho*Wo
   int chunk;         // pixels per grid.z slice (multiple of BKP)
   int ksplit;
-  int tiles_n;
+  int tiles_m, tiles_n, xcd_swizzle;
   float beta, scale; // applied only when ksplit == 1
   unsigned x_bytes, dy_bytes;
   unsigned mul_hw, sh_hw, mul_w, sh_w;   // magic-number division by Ho*Wo and Wo (dividends < 2^31)
@@ -54,11 +54,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave % WAVES_K, wmn = wave / WAVES_K;
   const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
-  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+  // 1-D grid, logical order (tile, tap, split) with the pixel split slowest; the XCD remap gives every XCD whole
+  // splits, so the workgroups that re-read the same x / dy chunk (all taps and channel tiles of a split) share an L2
+  const int L = p.xcd_swizzle ? bg::xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int ntile = p.tiles_m * p.tiles_n, ntap = p.k * p.k;
+  const int tile = L % ntile, tap = (L / ntile) % ntap, zsplit = L / (ntile * ntap);
+  const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
   const int ci0 = tile_m * BM, co0 = tile_n * BN;
-  const int tap = blockIdx.y;
   const int kh = tap / p.k, kw = tap % p.k;
-  const int m_begin = blockIdx.z * p.chunk;
+  const int m_begin = zsplit * p.chunk;
   const int m_end = min(p.M, m_begin + p.chunk);
   const int nsteps = (m_end - m_begin + BKP - 1) / BKP;
 
@@ -192,7 +196,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
         lstore(cur ^ 1);
         gload(step + 2);
       }
+#ifndef BG_WGRAD_INTERLEAVE
       __builtin_amdgcn_sched_barrier(0);
+#else
+      if (grp != NG / 2) __builtin_amdgcn_sched_barrier(0);      // middle group: loader VALU may interleave with its MFMAs
+#endif
 #pragma unroll
       for (int q = 0; q < PF; ++q)
 #pragma unroll
@@ -229,7 +237,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
     }
   }
 
-  float* out = p.out + (size_t)blockIdx.z * p.k * p.k * p.Ci * p.Co + (size_t)tap * p.Ci * p.Co;
+  float* out = p.out + (size_t)zsplit * p.k * p.k * p.Ci * p.Co + (size_t)tap * p.Ci * p.Co;
   const bool direct = p.ksplit == 1;
 #pragma unroll
   for (int i = 0; i < MI; ++i)
@@ -267,10 +275,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tg_kernel(const WgradParams p)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wk = wave % WAVES_K, wn = wave / WAVES_K;
-  const int tile_m = blockIdx.x / p.tiles_n, tile_n = blockIdx.x % p.tiles_n;
+  const int L = p.xcd_swizzle ? bg::xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;   // (tile, kh, split), split slowest
+  const int ntile = p.tiles_m * p.tiles_n;
+  const int tile = L % ntile, kh = (L / ntile) % p.k, zsplit = L / (ntile * p.k);
+  const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
   const int ci0 = tile_m * BMc, co0 = tile_n * BN;
-  const int kh = blockIdx.y;
-  const int m_begin = blockIdx.z * p.chunk;
+  const int m_begin = zsplit * p.chunk;
   const int m_end = min(p.M, m_begin + p.chunk);
   const int nsteps = (m_end - m_begin + BKP - 1) / BKP;
 
@@ -415,7 +425,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tg_kernel(const WgradParams p)
   const int co = co0 + wn * 32 + (lane & 31);
 #pragma unroll
   for (int t = 0; t < TG; ++t) {
-    float* out = p.out + (size_t)blockIdx.z * p.k * p.k * p.Ci * p.Co + (size_t)(kh * p.k + t) * p.Ci * p.Co;
+    float* out = p.out + (size_t)zsplit * p.k * p.k * p.Ci * p.Co + (size_t)(kh * p.k + t) * p.Ci * p.Co;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int ci = ci0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
@@ -850,7 +860,12 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     p.x_bytes = (unsigned)((size_t)B * H * W * Cin * sizeof(float));
     p.dy_bytes = (unsigned)((size_t)p.M * Cout * sizeof(float));
   }
-  p.chunk = pl.chunk; p.ksplit = pl.ksplit; p.tiles_n = pl.tiles_n;
+  p.chunk = pl.chunk; p.ksplit = pl.ksplit; p.tiles_n = pl.tiles_n; p.tiles_m = pl.tiles_m;
+  {
+    static const int swz = getenv("BG_WGRAD_SWZ") ? atoi(getenv("BG_WGRAD_SWZ")) : 0;   // per-tap kernel: measured slower with the remap
+    static const int swz_tg = getenv("BG_WGRAD_SWZ_TG") ? atoi(getenv("BG_WGRAD_SWZ_TG")) : 1;
+    p.xcd_swizzle = (pl.mode == 6 || pl.mode == 7) ? swz_tg : swz;
+  }
   p.beta = beta; p.scale = scale;
   p.out = pl.ksplit > 1 ? static_cast<float*>(ws_d) : dw;
   const double flops = 2.0 * p.M * (double)nout;
@@ -862,14 +877,15 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
   } else {
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.taps_in_grid == 1 ? ksize * ksize : (pl.taps_in_grid == 2 ? ksize : 1), pl.ksplit);
     bg::Launch L(stream, pl.mode >= 20 ? "conv_wgrad_mfma_thin_co" : (pl.mode >= 10 ? "conv_wgrad_mfma_thin_ci" : "conv_wgrad_mfma"), flops, 0);
+    const dim3 grid1((unsigned)(grid.x * grid.y * grid.z));      // v3 / tg kernels decode (tile, tap, split) themselves
     switch (pl.mode) {
-      case 1: hipLaunchKernelGGL((conv_wgrad_v3_kernel<128, 128, 32, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
-      case 2: hipLaunchKernelGGL((conv_wgrad_v3_kernel<64, 64, 32, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
-      case 3: hipLaunchKernelGGL((conv_wgrad_v3_kernel<64, 32, 64, 2, 1, 2>), grid, dim3(256), 0, L.s, p); break;
-      case 4: hipLaunchKernelGGL((conv_wgrad_v3_kernel<32, 64, 64, 1, 2, 2>), grid, dim3(256), 0, L.s, p); break;
-      case 5: hipLaunchKernelGGL((conv_wgrad_v3_kernel<32, 32, 128, 1, 1, 4>), grid, dim3(256), 0, L.s, p); break;
-      case 6: hipLaunchKernelGGL((conv_wgrad_tg_kernel<5, 64, 2, 2>), grid, dim3(256), 0, L.s, p); break;
-      case 7: hipLaunchKernelGGL((conv_wgrad_tg_kernel<5, 32, 1, 4>), grid, dim3(256), 0, L.s, p); break;
+      case 1: hipLaunchKernelGGL((conv_wgrad_v3_kernel<128, 128, 32, 2, 2, 1>), grid1, dim3(256), 0, L.s, p); break;
+      case 2: hipLaunchKernelGGL((conv_wgrad_v3_kernel<64, 64, 32, 2, 2, 1>), grid1, dim3(256), 0, L.s, p); break;
+      case 3: hipLaunchKernelGGL((conv_wgrad_v3_kernel<64, 32, 64, 2, 1, 2>), grid1, dim3(256), 0, L.s, p); break;
+      case 4: hipLaunchKernelGGL((conv_wgrad_v3_kernel<32, 64, 64, 1, 2, 2>), grid1, dim3(256), 0, L.s, p); break;
+      case 5: hipLaunchKernelGGL((conv_wgrad_v3_kernel<32, 32, 128, 1, 1, 4>), grid1, dim3(256), 0, L.s, p); break;
+      case 6: hipLaunchKernelGGL((conv_wgrad_tg_kernel<5, 64, 2, 2>), grid1, dim3(256), 0, L.s, p); break;
+      case 7: hipLaunchKernelGGL((conv_wgrad_tg_kernel<5, 32, 1, 4>), grid1, dim3(256), 0, L.s, p); break;
       case 10: hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 64, 1, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
       case 11: hipLaunchKernelGGL((conv_wgrad_kernel<96, 32, 64, 1, 1, 4, 1>), grid, dim3(256), 0, L.s, p); break;
       case 12: hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 64, 1, 1, 4, 1>), grid, dim3(256), 0, L.s, p); break;
