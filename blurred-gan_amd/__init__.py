@@ -4,7 +4,7 @@ Import as ``blurred_gan_amd`` (the repo-root shim maps that name onto this direc
 is not a valid Python identifier).  Module names mirror the reference repository: ``wgan``,
 ``blurred_gan``, ``gaussian_blur``, ``callbacks``, ``utils``; ``layers`` stands in for
 ``tensorflow.keras.layers``."""
-from . import layers, utils, dist, gaussian_blur, wgan, blurred_gan, callbacks, models, checkpoint  # noqa: F401
+from . import layers, utils, dist, gaussian_blur, wgan, blurred_gan, callbacks, models, checkpoint, metrics, sliced_wasserstein  # noqa: F401
 from .layers import set_seed, Sequential  # noqa: F401
 from .gaussian_blur import GaussianBlur2D, blur_images  # noqa: F401
 from .wgan import WGAN, WGANGP, TrainingConfig, gradient_penalty  # noqa: F401
