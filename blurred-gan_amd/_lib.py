@@ -58,6 +58,7 @@ SIGNATURES = {
     "bg_scale_f32": (_i, [_p, _f, _z, _p]),
     "bg_wgangp_d_loss": (_i, [_p, _p, _p, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
     "bg_wgan_g_loss": (_i, [_p, _i, _f, _p, _p, _p]),
+    "bg_u8_normalize_resize_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "bg_adam_f32": (_i, [_p, _p, _p, _p, _z, _f, _f, _f, _f, _p]),
     "bg_uniform_f32": (_i, [_p, _z, _u64, _u64, _p]),
     "bg_keep_mask_u8": (_i, [_p, _z, _f, _u64, _u64, _p]),

@@ -181,3 +181,65 @@ class LogMetricsCallback(ExecuteEveryNExamplesCallback):
             for name, value in logs.items():
                 if name not in ("batch", "size"):
                     w.scalar(f"{prefix}{name}", value, step=int(self.model.n_img))
+
+
+class FeedImagesToMetricCallback(ExecuteEveryNExamplesCallback):
+    """callbacks.py:138-184: every ``every_n_examples`` start recording ``model.images`` until ``num_samples`` have been
+    fed to ``metric.update_state(reals, fakes)``, then write the result and reset."""
+
+    def __init__(self, metric, image_preprocessing_fn, num_samples=1000, every_n_examples=10_000):
+        super().__init__(n=every_n_examples, starting_from=-num_samples)
+        self.num_samples_per_measurement = num_samples
+        self.recording = False
+        self.samples_recorded = 0
+        self.image_preprocessing_fn = image_preprocessing_fn
+        self.metric = metric
+        self.results = []
+
+    def function(self, batch, logs):
+        self.recording = True
+
+    def on_batch_end(self, batch: int, logs: Dict):
+        super().on_batch_end(batch, logs)
+        if not self.recording:
+            return
+        fakes, reals = self.model.images
+        n = min(logs["size"], self.num_samples_per_measurement - self.samples_recorded)
+        self.metric.update_state(self.image_preprocessing_fn(reals[:n]), self.image_preprocessing_fn(fakes[:n]))
+        self.samples_recorded += n
+        if self.samples_recorded >= self.num_samples_per_measurement:
+            assert self.samples_recorded == self.num_samples_per_measurement
+            self.write_result()
+            self.recording = False
+            self.metric.reset_states()
+            self.samples_recorded = 0
+
+    def write_result(self):
+        result = self.metric.result()
+        self.results.append(result)
+        with self.model.summary_writer.as_default() as w:
+            w.scalar(self.metric.name, result, step=int(self.model.n_img))
+
+
+class SWDMetricCallback(FeedImagesToMetricCallback):
+    """callbacks.py:186-198 (the reference's ``write_result`` reads an undefined ``self.swd_metric``; fixed)."""
+
+    def __init__(self, image_preprocessing_fn, num_samples=1000, every_n_examples=10_000, seed=None):
+        from .metrics import SWDMetric
+        super().__init__(SWDMetric(seed=seed), image_preprocessing_fn, num_samples=num_samples, every_n_examples=every_n_examples)
+
+    def write_result(self):
+        results = self.metric.results()
+        self.results.append(results)
+        print(" - " + " - ".join(f"{name}: {value:.4f}" for name, value in results.items()))
+        with self.model.summary_writer.as_default() as w:
+            for name, value in results.items():
+                w.scalar(f"swd/{name}", value, step=int(self.model.n_img))
+
+
+class FIDMetricCallback(FeedImagesToMetricCallback):
+    """callbacks.py:201-206 with the feature extractor injected (the reference downloads Inception-v3 from tfhub.dev)."""
+
+    def __init__(self, image_preprocessing_fn, feature_extractor, num_samples=1000, every_n_examples=10_000):
+        from .metrics import FIDMetric
+        super().__init__(FIDMetric(feature_extractor), image_preprocessing_fn, num_samples=num_samples, every_n_examples=every_n_examples)

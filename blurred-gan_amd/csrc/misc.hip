@@ -421,6 +421,31 @@ __global__ __launch_bounds__(kT) void g_loss_kernel(const float* __restrict__ s,
   }
 }
 
+// ---------------------------------------------------------------- input pipeline: u8 -> normalised f32 (+ bilinear resize)
+__global__ __launch_bounds__(kT) void u8_normalize_resize_kernel(const uint8_t* __restrict__ src, float* __restrict__ dst, size_t total,
+                                                                 int Hs, int Ws, int C, int Hd, int Wd, float sy, float sx) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < total; e += (size_t)gridDim.x * kT) {
+    const int c = (int)(e % C);
+    size_t t = e / C;
+    const int x = (int)(t % Wd);
+    t /= Wd;
+    const int y = (int)(t % Hd);
+    const int b = (int)(t / Hd);
+    // [TF] resize_bilinear, half_pixel_centers: in = (out + 0.5) * scale - 0.5; lower = max(floor(in), 0),
+    // upper = min(ceil(in), size - 1), lerp = in - floor(in)
+    const float fy = ((float)y + 0.5f) * sy - 0.5f, fx = ((float)x + 0.5f) * sx - 0.5f;
+    const float fy0 = floorf(fy), fx0 = floorf(fx);
+    const int y0 = max((int)fy0, 0), y1 = min((int)ceilf(fy), Hs - 1);
+    const int x0 = max((int)fx0, 0), x1 = min((int)ceilf(fx), Ws - 1);
+    const float ly = fy - fy0, lx = fx - fx0;
+    const uint8_t* img = src + (size_t)b * Hs * Ws * C + c;
+    auto px = [&](int yy, int xx) { return ((float)img[((size_t)yy * Ws + xx) * C] - 127.5f) / 127.5f; };
+    const float top = px(y0, x0) + (px(y0, x1) - px(y0, x0)) * lx;
+    const float bot = px(y1, x0) + (px(y1, x1) - px(y1, x0)) * lx;
+    dst[e] = top + (bot - top) * ly;
+  }
+}
+
 // ---------------------------------------------------------------- Adam
 __global__ __launch_bounds__(kT) void adam_kernel(float* __restrict__ theta, float* __restrict__ m, float* __restrict__ v,
                                                   const float* __restrict__ g, size_t n, float lr_t, float b1, float b2, float eps) {
@@ -673,6 +698,16 @@ int bg_wgan_g_loss(const float* s, int B, float inv_gbs, float* ds, float* metri
   bg::Launch L(stream, "g_loss", 0, 0);
   hipLaunchKernelGGL(g_loss_kernel, dim3(1), dim3(kT), 0, L.s, s, B, inv_gbs, ds, metrics_d);
   return L.done("g_loss_kernel");
+}
+
+int bg_u8_normalize_resize_f32(const uint8_t* src, float* dst, int B, int Hs, int Ws, int C, int Hd, int Wd, void* stream) {
+  BG_REQUIRE(src && dst, BG_ERR_NULL, "bg_u8_normalize_resize_f32: null pointer");
+  BG_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && C > 0 && Hd > 0 && Wd > 0, BG_ERR_BAD_SHAPE, "bg_u8_normalize_resize_f32: B=%d %dx%dx%d -> %dx%d", B, Hs, Ws, C, Hd, Wd);
+  const size_t total = (size_t)B * Hd * Wd * C;
+  bg::Launch L(stream, "u8_normalize_resize", 0, (double)B * Hs * Ws * C + 4.0 * total);
+  hipLaunchKernelGGL(u8_normalize_resize_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, src, dst, total, Hs, Ws, C, Hd, Wd,
+                     (float)Hs / (float)Hd, (float)Ws / (float)Wd);
+  return L.done("u8_normalize_resize_kernel");
 }
 
 int bg_adam_f32(float* theta, float* m, float* v, const float* g, size_t n, float lr_t, float b1, float b2, float eps,

@@ -239,6 +239,16 @@ def wgan_g_loss(s, inv_gbs, ds, metrics):
     check(_lib.load().bg_wgan_g_loss(_ptr(s), s.numel(), inv_gbs, _ptr(ds), _ptr(metrics), _stream()), "bg_wgan_g_loss")
 
 
+def u8_normalize_resize(src_u8, dst):
+    """uint8 NHWC -> float32 NHWC in [-1, 1], bilinear-resized to dst's spatial size (demo_celeba.py:22-35)."""
+    assert src_u8.dtype == torch.uint8 and dst.dtype == torch.float32
+    B, Hs, Ws, Cc = src_u8.shape
+    assert dst.shape[0] == B and dst.shape[3] == Cc
+    check(_lib.load().bg_u8_normalize_resize_f32(_ptr(src_u8), _ptr(dst), B, Hs, Ws, Cc, dst.shape[1], dst.shape[2], _stream()),
+          "bg_u8_normalize_resize_f32")
+    return dst
+
+
 def adam(theta, m, v, g, lr_t, b1=0.9, b2=0.999, eps=1e-7):
     assert theta.numel() == m.numel() == v.numel() == g.numel()
     check(_lib.load().bg_adam_f32(_ptr(theta), _ptr(m), _ptr(v), _ptr(g), theta.numel(), lr_t, b1, b2, eps, _stream()), "bg_adam_f32")

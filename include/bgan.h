@@ -164,6 +164,11 @@ int bg_wgangp_d_loss(const float* fs, const float* rs, const float* norm_b, int 
 /* metrics_d[0] = mean(s), metrics_d[1] = -sum(s)*inv_gbs ; ds[b] = -inv_gbs */
 int bg_wgan_g_loss(const float* s, int B, float inv_gbs, float* ds, float* metrics_d, void* stream);
 
+/* ---- input pipeline (demo_celeba.py:22-35, demo_mnist.py:24-31): uint8 NHWC -> float32, (x - 127.5) / 127.5, then
+ *      tf.image.resize(bilinear, half-pixel centres) to [Hd, Wd] (normalise BEFORE resize, aspect not preserved).
+ *      Hd == Hs && Wd == Ws is the MNIST pipeline (normalise only). */
+int bg_u8_normalize_resize_f32(const uint8_t* src, float* dst, int B, int Hs, int Ws, int C, int Hd, int Wd, void* stream);
+
 /* ---- optimiser: tf.keras.optimizers.Adam (wgan.py:56-61,141,167) ----------------------------- */
 /* lr_t = lr*sqrt(1-b2^t)/(1-b1^t) is computed by the caller (host) per step. */
 int bg_adam_f32(float* theta, float* m, float* v, const float* g, size_t n, float lr_t, float b1, float b2,

@@ -249,3 +249,26 @@ def exponential_decay(initial, step, decay_steps, rate):
     """[TF] ExponentialDecay(staircase=False) as used by callbacks.py:51-57, float32."""
     p = np.float32(step) / np.float32(decay_steps)
     return float(np.float32(initial) * np.float32(np.power(np.float32(rate), p)))
+
+
+# ----------------------------------------------------------------------------
+# Input pipeline (demo_celeba.py:22-35): normalise, then [TF] tf.image.resize bilinear (half-pixel centres)
+# ----------------------------------------------------------------------------
+def normalize_resize_bilinear(img_u8, out_hw, dtype=np.float64):
+    """uint8 NHWC -> (x - 127.5) / 127.5 -> bilinear resize to out_hw.  [TF] resize_bilinear(half_pixel_centers=True):
+    in = (out + 0.5) * scale - 0.5, lower = max(floor(in), 0), upper = min(ceil(in), size - 1), lerp = in - floor(in)."""
+    x = (img_u8.astype(dtype) - dtype(127.5)) / dtype(127.5)
+    B, Hs, Ws, C = x.shape
+    Hd, Wd = out_hw
+
+    def weights(n_out, n_in):
+        pos = (np.arange(n_out, dtype=dtype) + dtype(0.5)) * dtype(n_in / n_out) - dtype(0.5)
+        lo_f = np.floor(pos)
+        lo = np.maximum(lo_f, 0).astype(int)
+        hi = np.minimum(np.ceil(pos), n_in - 1).astype(int)
+        return lo, hi, (pos - lo_f).astype(dtype)
+    y0, y1, ly = weights(Hd, Hs)
+    x0, x1, lx = weights(Wd, Ws)
+    top = x[:, y0][:, :, x0] + (x[:, y0][:, :, x1] - x[:, y0][:, :, x0]) * lx[None, None, :, None]
+    bot = x[:, y1][:, :, x0] + (x[:, y1][:, :, x1] - x[:, y1][:, :, x0]) * lx[None, None, :, None]
+    return top + (bot - top) * ly[None, :, None, None]

