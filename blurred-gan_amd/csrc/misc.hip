@@ -259,6 +259,33 @@ __global__ __launch_bounds__(kT) void bn_stats_final_kernel(const float* __restr
   }
 }
 
+// sums[q*C + c] = sum over blocks of partial[(b*2 + q)*C + c]   (one wave per channel)
+__global__ __launch_bounds__(kT) void partials_to_sums_kernel(const float* __restrict__ partial, int nblk, int C, float* sums) {
+  const int c = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
+  if (c >= C) return;
+  const float s0 = wave_sum_partials(partial, nblk, 2, 0, C, c), s1 = wave_sum_partials(partial, nblk, 2, 1, C, c);
+  if ((threadIdx.x & 63) == 0) {
+    sums[c] = s0;
+    sums[C + c] = s1;
+  }
+}
+
+__global__ __launch_bounds__(kT) void bn_finalize_sums_kernel(const float* __restrict__ sums, int M, int C, float* save_mean,
+                                                              float* save_inv, float* moving_mean, float* moving_var, float eps,
+                                                              float momentum, int unbiased) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c >= C) return;
+  const float mean = sums[c] / (float)M;
+  const float var = fmaxf(sums[C + c] / (float)M - mean * mean, 0.f);
+  save_mean[c] = mean;
+  save_inv[c] = 1.0f / sqrtf(var + eps);
+  if (moving_mean) {
+    const float vu = unbiased ? var * ((float)M / (float)max(M - 1, 1)) : var;
+    moving_mean[c] = moving_mean[c] * momentum + mean * (1.f - momentum);
+    moving_var[c] = moving_var[c] * momentum + vu * (1.f - momentum);
+  }
+}
+
 // y = lrelu(gamma*(x-mean)*inv + beta); mean/inv either saved batch stats or derived from moving stats
 __global__ __launch_bounds__(kT) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int C,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -294,7 +321,7 @@ __global__ __launch_bounds__(kT) void bn_bwd_final_kernel(const float* __restric
 }
 
 __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                          const float* __restrict__ x, float* __restrict__ dx, size_t total, int M, int C,
+                                                          const float* __restrict__ x, float* __restrict__ dx, size_t total, int M /* rows behind the statistics */, int C,
                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
                                                           const float* __restrict__ inv, const float* __restrict__ dgamma,
                                                           const float* __restrict__ dbeta, float alpha) {
@@ -622,6 +649,80 @@ int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, 
   bg::Launch L(stream, "bn_bwd_apply", 0, 16.0 * total);
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M, C, gamma, save_mean, save_inv,
                      dgamma, dbeta, lrelu_alpha);
+  return L.done("bn_bwd_apply_kernel");
+}
+
+static int bn_partials(const char* fn, const float* x, int M, int C, float* partial, void* stream) {
+  const int nblk = red_blocks(M, C);
+  bg::Launch L(stream, "bn_stats_partial", 0, 4.0 * M * C);
+  if (flat_ok(M, C) && bg::aligned16(x)) hipLaunchKernelGGL(bn_stats_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, x, M, C, partial);
+  else hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, x, M, C, partial);
+  return L.done(fn);
+}
+
+int bg_bn_stats_f32(const float* x, int M, int C, float* sums_d, void* ws_d, size_t ws_bytes, void* stream) {
+  BG_REQUIRE(x && sums_d, BG_ERR_NULL, "bg_bn_stats_f32: null pointer");
+  BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_stats_f32: M=%d C=%d", M, C);
+  BG_REQUIRE(ws_d && ws_bytes >= bg_bn_workspace_bytes(M, C), BG_ERR_WORKSPACE, "bg_bn_stats_f32: workspace too small");
+  float* partial = static_cast<float*>(ws_d);
+  int rc = bn_partials("bn_stats_partial_kernel", x, M, C, partial, stream);
+  if (rc) return rc;
+  bg::Launch L(stream, "bn_partials_to_sums", 0, 0);
+  hipLaunchKernelGGL(partials_to_sums_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, red_blocks(M, C), C, sums_d);
+  return L.done("partials_to_sums_kernel");
+}
+
+int bg_bn_finalize_f32(const float* sums_d, int M_total, int C, float* save_mean, float* save_inv, float* moving_mean,
+                       float* moving_var, float eps, float momentum, int unbiased, void* stream) {
+  BG_REQUIRE(sums_d && save_mean && save_inv, BG_ERR_NULL, "bg_bn_finalize_f32: null pointer");
+  BG_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), BG_ERR_NULL, "bg_bn_finalize_f32: moving_mean/var must both be given or both NULL");
+  BG_REQUIRE(M_total > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_finalize_f32: M_total=%d C=%d", M_total, C);
+  bg::Launch L(stream, "bn_finalize", 0, 0);
+  hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, sums_d, M_total, C, save_mean, save_inv, moving_mean,
+                     moving_var, eps, momentum, unbiased);
+  return L.done("bn_finalize_sums_kernel");
+}
+
+int bg_bn_apply_f32(const float* x, float* y, int M, int C, const float* gamma, const float* beta, const float* mean,
+                    const float* inv, float lrelu_alpha, void* stream) {
+  BG_REQUIRE(x && y && gamma && beta && mean && inv, BG_ERR_NULL, "bg_bn_apply_f32: null pointer");
+  BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_apply_f32: M=%d C=%d", M, C);
+  const size_t total = (size_t)M * C;
+  bg::Launch L(stream, "bn_apply_lrelu", 0, 8.0 * total);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, mean, inv, 0, 0.f, lrelu_alpha);
+  return L.done("bn_apply_kernel");
+}
+
+int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, int C, const float* save_mean,
+                        const float* save_inv, float lrelu_alpha, float* sums_d, void* ws_d, size_t ws_bytes, void* stream) {
+  BG_REQUIRE(dy && y && x && save_mean && save_inv && sums_d, BG_ERR_NULL, "bg_bn_bwd_stats_f32: null pointer");
+  BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_bwd_stats_f32: M=%d C=%d", M, C);
+  BG_REQUIRE(ws_d && ws_bytes >= bg_bn_workspace_bytes(M, C), BG_ERR_WORKSPACE, "bg_bn_bwd_stats_f32: workspace too small");
+  const int nblk = red_blocks(M, C);
+  float* partial = static_cast<float*>(ws_d);
+  {
+    bg::Launch L(stream, "bn_bwd_partial", 0, 12.0 * M * C);
+    if (flat_ok(M, C) && bg::aligned16(dy) && bg::aligned16(y) && bg::aligned16(x) && bg::aligned16(save_mean) && bg::aligned16(save_inv))
+      hipLaunchKernelGGL(bn_bwd_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv, lrelu_alpha, partial);
+    else
+      hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv,
+                         lrelu_alpha, partial);
+    int rc = L.done("bn_bwd_partial_kernel");
+    if (rc) return rc;
+  }
+  bg::Launch L(stream, "bn_partials_to_sums", 0, 0);
+  hipLaunchKernelGGL(partials_to_sums_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, nblk, C, sums_d);
+  return L.done("partials_to_sums_kernel");
+}
+
+int bg_bn_bwd_apply_f32(const float* dy, const float* y, const float* x, float* dx, int M, int M_total, int C, const float* gamma,
+                        const float* save_mean, const float* save_inv, const float* sums_d, float lrelu_alpha, void* stream) {
+  BG_REQUIRE(dy && y && x && dx && gamma && save_mean && save_inv && sums_d, BG_ERR_NULL, "bg_bn_bwd_apply_f32: null pointer");
+  BG_REQUIRE(M > 0 && M_total >= M && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_bwd_apply_f32: M=%d M_total=%d C=%d", M, M_total, C);
+  const size_t total = (size_t)M * C;
+  bg::Launch L(stream, "bn_bwd_apply", 0, 16.0 * total);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M_total, C, gamma, save_mean, save_inv,
+                     sums_d + C /* dgamma = sum dz*xhat */, sums_d /* dbeta = sum dz */, lrelu_alpha);
   return L.done("bn_bwd_apply_kernel");
 }
 

@@ -15,7 +15,7 @@ from typing import List, Optional
 import numpy as np
 import torch
 
-from . import ops
+from . import dist, ops
 from ._lib import EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH
 
 
@@ -55,12 +55,19 @@ class Context:
             self.inv.append(f(c) if st.bn is not None else None)
             self.keep.append(torch.empty((B,) + st.out_shape, dtype=torch.uint8, device=device) if st.drop else None)
         self._net, self._device = net, device
+        self._extra = {}
         self.dropout_active = False
 
     def buf(self, lst, i):
         if lst[i] is None:
             lst[i] = torch.empty((self.B,) + self._net.stages[i].out_shape, dtype=torch.float32, device=self._device)
         return lst[i]
+
+    def bn_sums(self, i, C):
+        key = ("bn_sums", i)
+        if key not in self._extra:
+            self._extra[key] = torch.empty(2 * C, dtype=torch.float32, device=self._device)
+        return self._extra[key]
 
     def input_grad(self):
         if self.din is None:
@@ -113,6 +120,7 @@ class Net:
         self._taps_cache = {}
         self._splitk_bytes = {}
         self.rng_offset = 0
+        self.sync_bn = True       # data parallel: BatchNormalization statistics over the global batch
 
     # ------------------------------------------------------------------ resources
     def context(self, B, tag="default") -> Context:
@@ -231,7 +239,16 @@ class Net:
                 C = st.out_shape[-1]
                 M = tgt.numel() // C
                 bn = st.bn
-                if training:
+                if training and self.sync_bn and dist.world_size() > 1:
+                    # SyncBN: batch statistics over the GLOBAL batch -- all-reduce the per-channel sums
+                    ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
+                    sums = ctx.bn_sums(i, C)
+                    ops.bn_stats(tgt, M, C, sums, ws)
+                    dist.all_reduce_sum_(sums)
+                    ops.bn_finalize(sums, M * dist.world_size(), C, ctx.mean[i], ctx.inv[i], bn.vars["moving_mean"],
+                                    bn.vars["moving_variance"], eps=bn.epsilon, momentum=bn.momentum, unbiased=(len(st.out_shape) == 3))
+                    ops.bn_apply(tgt, out, M, C, bn.vars["gamma"], bn.vars["beta"], ctx.mean[i], ctx.inv[i], lrelu_alpha=st.alpha)
+                elif training:
                     ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
                     ops.bn_train_fwd(tgt, out, M, C, bn.vars["gamma"], bn.vars["beta"], bn.vars["moving_mean"],
                                      bn.vars["moving_variance"], ctx.mean[i], ctx.inv[i], ws, eps=bn.epsilon,
@@ -268,8 +285,21 @@ class Net:
                 ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
                 dg = st_.grad_of(st.bn, "gamma") if need_dw else torch.empty(C, device=self.device)
                 db = st_.grad_of(st.bn, "beta") if need_dw else torch.empty(C, device=self.device)
-                ops.bn_train_bwd(gv, ctx.a[i], ctx.z[i], dz, M, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], dg, db, ws,
-                                 lrelu_alpha=st.alpha)
+                if self.sync_bn and dist.world_size() > 1:
+                    world = dist.world_size()
+                    sums = ctx.bn_sums(i, C)
+                    ops.bn_bwd_stats(gv, ctx.a[i], ctx.z[i], M, C, ctx.mean[i], ctx.inv[i], sums, ws, lrelu_alpha=st.alpha)
+                    dist.all_reduce_sum_(sums)
+                    ops.bn_bwd_apply(gv, ctx.a[i], ctx.z[i], dz, M, M * world, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], sums,
+                                     lrelu_alpha=st.alpha)
+                    if need_dw:     # the sums are already global: pre-divide so the flat gradient SUM all-reduce restores them
+                        db.copy_(sums[:C])
+                        dg.copy_(sums[C:])
+                        ops.scale_(db, 1.0 / world)
+                        ops.scale_(dg, 1.0 / world)
+                else:
+                    ops.bn_train_bwd(gv, ctx.a[i], ctx.z[i], dz, M, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], dg, db, ws,
+                                     lrelu_alpha=st.alpha)
             elif st.act == "lrelu":
                 if g_is_dz:
                     dz = gv

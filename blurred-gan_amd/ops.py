@@ -181,6 +181,34 @@ def bn_train_bwd(dy, y, x, dx, M, Cc, gamma, save_mean, save_inv, dgamma, dbeta,
     return dx
 
 
+def bn_stats(x, M, Cc, sums, ws):
+    check(_lib.load().bg_bn_stats_f32(_ptr(x), M, Cc, _ptr(sums), _ptr(ws), ws.numel() * ws.element_size(), _stream()), "bg_bn_stats_f32")
+    return sums
+
+
+def bn_finalize(sums, M_total, Cc, save_mean, save_inv, moving_mean, moving_var, eps=1e-3, momentum=0.99, unbiased=True):
+    check(_lib.load().bg_bn_finalize_f32(_ptr(sums), M_total, Cc, _ptr(save_mean), _ptr(save_inv), _ptr(moving_mean), _ptr(moving_var),
+                                         eps, momentum, int(unbiased), _stream()), "bg_bn_finalize_f32")
+
+
+def bn_apply(x, y, M, Cc, gamma, beta, mean, inv, lrelu_alpha=LRELU_ALPHA):
+    check(_lib.load().bg_bn_apply_f32(_ptr(x), _ptr(y), M, Cc, _ptr(gamma), _ptr(beta), _ptr(mean), _ptr(inv), lrelu_alpha, _stream()),
+          "bg_bn_apply_f32")
+    return y
+
+
+def bn_bwd_stats(dy, y, x, M, Cc, save_mean, save_inv, sums, ws, lrelu_alpha=LRELU_ALPHA):
+    check(_lib.load().bg_bn_bwd_stats_f32(_ptr(dy), _ptr(y), _ptr(x), M, Cc, _ptr(save_mean), _ptr(save_inv), lrelu_alpha, _ptr(sums),
+                                          _ptr(ws), ws.numel() * ws.element_size(), _stream()), "bg_bn_bwd_stats_f32")
+    return sums
+
+
+def bn_bwd_apply(dy, y, x, dx, M, M_total, Cc, gamma, save_mean, save_inv, sums, lrelu_alpha=LRELU_ALPHA):
+    check(_lib.load().bg_bn_bwd_apply_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(dx), M, M_total, Cc, _ptr(gamma), _ptr(save_mean),
+                                          _ptr(save_inv), _ptr(sums), lrelu_alpha, _stream()), "bg_bn_bwd_apply_f32")
+    return dx
+
+
 # ------------------------------------------------------------------ pointwise / losses / adam / rng
 def lerp(r, f, alpha_b, out):
     B = r.shape[0]

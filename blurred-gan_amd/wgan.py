@@ -102,7 +102,8 @@ class WGAN:
     uses_gradient_penalty = False
 
     def __init__(self, generator: Sequential, discriminator: Sequential, hyperparams: "WGAN.HyperParameters",
-                 config: TrainingConfig, *args, reproduce_vector_loss_quirk: bool = True, sync_metrics: bool = True, **kwargs):
+                 config: TrainingConfig, *args, reproduce_vector_loss_quirk: bool = True, sync_metrics: bool = True,
+                 sync_batchnorm: bool = True, **kwargs):
         self.hparams = hyperparams
         if str(self.hparams.optimizer).lower() != "adam":
             raise NotImplementedError("only the reference's default optimizer 'adam' is implemented (wgan.py:43,56)")
@@ -128,6 +129,7 @@ class WGAN:
         # --- build-side switches (documented in DESIGN.md)
         self.reproduce_vector_loss_quirk = reproduce_vector_loss_quirk
         self.sync_metrics = sync_metrics     # False: skip the per-step device->host metric read (bench)
+        self.sync_batchnorm = sync_batchnorm  # DP: generator BN statistics over the global batch (False = per replica)
         self._rng_seed = get_seed()
         self._rng_off = 0
         self._bufs = {}
@@ -304,6 +306,7 @@ class WGAN:
         z = self._inj("z_g")
         z = self._as_device(z) if z is not None else self._uniform("z_g", (B, self.latent_size))
         cg = G.context(B, "g")
+        G.sync_bn = self.sync_batchnorm
         fakes = G.forward(cg, z, training=True)
         chat = D.context(B, "hat")
         s = D.forward(chat, fakes, training=False).view(B)

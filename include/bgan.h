@@ -136,6 +136,19 @@ int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, 
                     const float* gamma, const float* save_mean, const float* save_inv,
                     float* dgamma, float* dbeta, float lrelu_alpha, void* ws_d, size_t ws_bytes, void* stream);
 
+/* The same BatchNormalization in separable pieces, for data-parallel SyncBN: the per-channel sums are
+ * all-reduced by the caller between the pieces.  sums_d = [2*C]: forward {sum x, sum x^2}; backward {sum dz, sum dz*xhat}
+ * with dz = dy * lrelu'(y).  M_total = rows summed over all replicas. */
+int bg_bn_stats_f32(const float* x, int M, int C, float* sums_d, void* ws_d, size_t ws_bytes, void* stream);
+int bg_bn_finalize_f32(const float* sums_d, int M_total, int C, float* save_mean, float* save_inv, float* moving_mean,
+                       float* moving_var, float eps, float momentum, int unbiased, void* stream);
+int bg_bn_apply_f32(const float* x, float* y, int M, int C, const float* gamma, const float* beta, const float* mean,
+                    const float* inv, float lrelu_alpha, void* stream);
+int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, int C, const float* save_mean,
+                        const float* save_inv, float lrelu_alpha, float* sums_d, void* ws_d, size_t ws_bytes, void* stream);
+int bg_bn_bwd_apply_f32(const float* dy, const float* y, const float* x, float* dx, int M, int M_total, int C, const float* gamma,
+                        const float* save_mean, const float* save_inv, const float* sums_d, float lrelu_alpha, void* stream);
+
 /* ---- pointwise ------------------------------------------------------------------------------ */
 /* wgan.py:239: xhat[b,:] = r[b,:] + alpha[b] * (f[b,:] - r[b,:]) */
 int bg_lerp_f32(const float* r, const float* f, const float* alpha_b, float* xhat, int B, int n_per, void* stream);

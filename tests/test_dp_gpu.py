@@ -55,6 +55,10 @@ def _worker(rank, world, port, out_dir):
     st = gan.discriminator.store
     np.save(os.path.join(out_dir, f"d_grad_{rank}.npy"), st.grad[:st.n_train].cpu().numpy())
     np.save(os.path.join(out_dir, f"d_theta_{rank}.npy"), st.theta[:st.n_train].cpu().numpy())
+    sg = gan.generator.store
+    np.save(os.path.join(out_dir, f"g_grad_{rank}.npy"), sg.grad[:sg.n_train].cpu().numpy())
+    np.save(os.path.join(out_dir, f"g_theta_{rank}.npy"), sg.theta[:sg.n_train].cpu().numpy())
+    np.save(os.path.join(out_dir, f"g_state_{rank}.npy"), sg.state[:sg.n_state].cpu().numpy())
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
 
@@ -72,3 +76,13 @@ def test_two_ranks_match_single_process_global_batch(tmp_path):
     t0, t1 = np.load(tmp_path / "d_theta_0.npy"), np.load(tmp_path / "d_theta_1.npy")
     np.testing.assert_array_equal(t0, t1)                                   # replicas stay in lock step
     np.testing.assert_allclose(t0, ref_t, rtol=1e-3, atol=2e-4)
+    # generator: SyncBN makes the 2-replica step equal to the single-device step at the global batch (SURVEY.md 8e iii)
+    sg = gan.generator.store
+    rg = sg.grad[:sg.n_train].cpu().numpy()
+    gg0, gg1 = np.load(tmp_path / "g_grad_0.npy"), np.load(tmp_path / "g_grad_1.npy")
+    np.testing.assert_array_equal(gg0, gg1)
+    np.testing.assert_allclose(gg0, rg, rtol=5e-3, atol=5e-4 * np.abs(rg).max())
+    np.testing.assert_allclose(np.load(tmp_path / "g_theta_0.npy"), sg.theta[:sg.n_train].cpu().numpy(), rtol=1e-3, atol=3e-4)
+    s0, s1 = np.load(tmp_path / "g_state_0.npy"), np.load(tmp_path / "g_state_1.npy")
+    np.testing.assert_array_equal(s0, s1)
+    np.testing.assert_allclose(s0, sg.state[:sg.n_state].cpu().numpy(), rtol=1e-4, atol=1e-6)      # BN moving statistics

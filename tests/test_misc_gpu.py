@@ -150,3 +150,31 @@ def test_input_pipeline_kernel(src_hw, dst_hw, C):
     ref = O.normalize_resize_bilinear(img, dst_hw)
     np.testing.assert_allclose(dst.cpu().numpy(), ref, rtol=1e-5, atol=2e-6)
     assert dst.min().item() >= -1.0 - 1e-6 and dst.max().item() <= 1.0 + 1e-6
+
+
+def test_separable_batchnorm_pieces_equal_fused():
+    """The SyncBN entry points (stats -> [all-reduce] -> finalize -> apply; bwd stats -> [all-reduce] -> bwd apply) with a
+    single replica reproduce the fused bg_bn_train_fwd / bg_bn_train_bwd bit for bit."""
+    from blurred_gan_amd import ops
+    rng = np.random.default_rng(12)
+    shape, C = (32, 8, 8, 64), 64
+    M = int(np.prod(shape)) // C
+    x, dy = dev(rng.normal(size=shape) * 2 + 0.3), dev(rng.normal(size=shape))
+    gamma, beta = dev(1 + 0.2 * rng.normal(size=C)), dev(0.1 * rng.normal(size=C))
+    ws = torch.empty(ops._lib.load().bg_bn_workspace_bytes(M, C) // 4 + 4, device="cuda")
+    mm1, mv1, mm2, mv2 = (dev(np.zeros(C)), dev(np.ones(C)), dev(np.zeros(C)), dev(np.ones(C)))
+    y1, y2 = torch.empty(shape, device="cuda"), torch.empty(shape, device="cuda")
+    m1, i1, m2, i2 = (torch.empty(C, device="cuda") for _ in range(4))
+    ops.bn_train_fwd(x, y1, M, C, gamma, beta, mm1, mv1, m1, i1, ws)
+    sums = torch.empty(2 * C, device="cuda")
+    ops.bn_stats(x, M, C, sums, ws)
+    ops.bn_finalize(sums, M, C, m2, i2, mm2, mv2)
+    ops.bn_apply(x, y2, M, C, gamma, beta, m2, i2)
+    for a, b in ((y1, y2), (m1, m2), (i1, i2), (mm1, mm2), (mv1, mv2)):
+        assert torch.equal(a, b)
+    dx1, dx2 = torch.empty(shape, device="cuda"), torch.empty(shape, device="cuda")
+    dg, db = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_train_bwd(dy, y1, x, dx1, M, C, gamma, m1, i1, dg, db, ws)
+    ops.bn_bwd_stats(dy, y1, x, M, C, m1, i1, sums, ws)
+    ops.bn_bwd_apply(dy, y1, x, dx2, M, M, C, gamma, m1, i1, sums)
+    assert torch.equal(dx1, dx2) and torch.equal(db, sums[:C]) and torch.equal(dg, sums[C:])

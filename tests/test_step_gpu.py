@@ -114,3 +114,23 @@ def test_training_reduces_critic_loss_own_rng():
     assert abs(float(gan.std) - exp) < 1e-5
     s = gan.generate_samples(training=False)
     assert tuple(s.shape) == (B, 8, 8, 3) and torch.isfinite(s).all() and s.abs().max() <= 1.0
+
+
+def test_loss_curves_track_the_oracle_over_25_steps():
+    """Loss-curve parity (BASELINE.json: 'loss curves within tolerance of the CPU reference'): 25 consecutive steps with
+    injected randomness; every per-step metric of the HIP path stays within 1 % (+1e-3) of the float64 oracle's."""
+    arch, B = "tiny", 6
+    gan, st, reals, rng = _make(arch, B, 1.0, seed=21)
+    hp = dict(S.DEFAULT_HP, global_batch_size=B)
+    worst = 0.0
+    for it in range(25):
+        rnd = S.draw_randomness(arch, B, rng, np.float64)
+        r = rng.uniform(-1, 1, size=reals.shape)
+        st, met, _ = S.train_on_batch(st, r, rnd, hp)
+        got = dict(zip(gan.metrics_names, gan.train_on_batch(r.astype(np.float32), randomness=rnd)))
+        for k in ("disc_loss", "gen_loss", "gp_term", "real_scores", "fake_scores"):
+            err = abs(got[k] - met[k]) / (abs(met[k]) + 0.1)
+            worst = max(worst, err)
+            assert err < 1e-2, (it, k, got[k], met[k])
+    assert int(gan.n_batches) == 25
+    print("worst relative metric deviation over 25 steps:", worst)
