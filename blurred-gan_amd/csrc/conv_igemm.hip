@@ -96,36 +96,38 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   const int nsteps_all = g.ntaps * kchunks;
   const int s_begin = (int)((long)nsteps_all * split / p.ksplit);          // this workgroup's slice of the K steps
   const int nsteps = (int)((long)nsteps_all * (split + 1) / p.ksplit) - s_begin;
-  float4 regA[AP], regB[BP];
+  float4 regA0[AP], regB0[BP], regA1[AP], regB1[BP];     // two staging register sets (global loads run 2 steps ahead of their LDS write)
 
-  // Software pipeline (one barrier per step, loop body is a single basic block so the scheduler can slot the
-  // loader's VALU / VMEM / DS-write work between MFMAs):
-  //   step s:  MFMA(first half of tile s) | ds_write tile s+1 (its global loads were issued during step s-1)
-  //            | issue global loads of tile s+2 | MFMA(second half of tile s) | barrier
-  auto gload = [&](int lstep) {
+  // Software pipeline, one barrier per step, loop body branch-free (the scheduler slots the loader between MFMAs):
+  //   step s:  MFMA(first half of tile s) | ds_write tile s+1 (loaded during step s-2) | issue loads of tile s+3
+  //            | MFMA(second half of tile s) | barrier
+  // Loads therefore have two full steps (~2 x 1024 MFMA cycles) to return: enough for an L2 miss served by the
+  // Infinity Cache / HBM, which the weight-streaming small-M layers (K = 6400) hit on most steps.
+  auto gload = [&](int lstep, float4 (&rA)[AP], float4 (&rB)[BP]) {
     const int step = s_begin + lstep;
+    const bool live = lstep < nsteps;                         // padded step (odd counts): poisoned offsets load zeros
     const int tq = step / kchunks;
-    const int tp = g.tap[min(tq, g.ntaps - 1)];              // steps past the end re-load the last tap; never consumed
+    const int tp = g.tap[min(tq, g.ntaps - 1)];
     const int c0 = (step - tq * kchunks) * BK;
     const int dy = bg::tap_dy(tp), dx = bg::tap_dx(tp);
     const unsigned tapoff = (unsigned)(((dy * p.Ws + dx) * p.Ck + c0) * 4);
     const unsigned woff = (unsigned)((bg::tap_wi(tp) * p.N * p.Ck + c0) * 4);
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const bool ok = (unsigned)(a_y[i] + dy) < (unsigned)p.Hs && (unsigned)(a_x[i] + dx) < (unsigned)p.Ws;
-      regA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_off[i] + tapoff : kOob, 0, 0));
+      const bool ok = live && (unsigned)(a_y[i] + dy) < (unsigned)p.Hs && (unsigned)(a_x[i] + dx) < (unsigned)p.Ws;
+      rA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_off[i] + tapoff : kOob, 0, 0));
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i)
-      regB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, b_off[i] == kOob ? kOob : b_off[i] + woff, 0, 0));
+      rB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_off[i] == kOob || !live) ? kOob : b_off[i] + woff, 0, 0));
   };
-  auto lstore = [&](int buf) {
+  auto lstore = [&](int buf, const float4 (&rA)[AP], const float4 (&rB)[BP]) {
     float* sa = smem + buf * STAGE;
     float* sb = sa + BM * LD;
 #pragma unroll
-    for (int i = 0; i < AP; ++i) *reinterpret_cast<float4*>(sa + (lrow + i * RPP) * LD + lq * 4) = regA[i];
+    for (int i = 0; i < AP; ++i) *reinterpret_cast<float4*>(sa + (lrow + i * RPP) * LD + lq * 4) = rA[i];
 #pragma unroll
-    for (int i = 0; i < BP; ++i) *reinterpret_cast<float4*>(sb + (lrow + i * RPP) * LD + lq * 4) = regB[i];
+    for (int i = 0; i < BP; ++i) *reinterpret_cast<float4*>(sb + (lrow + i * RPP) * LD + lq * 4) = rB[i];
   };
 
   floatx16 acc[MI][NI];
@@ -136,17 +138,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(0);
-  lstore(0);
-  gload(1);
+  gload(0, regA0, regB0);
+  gload(1, regA1, regB1);
+  lstore(0, regA0, regB0);
+  gload(2, regA0, regB0);
   __syncthreads();
 
   const int frow = lane & 31, fk = (lane >> 5) * 4;
   const float* sa0 = smem + (wm * WTM + frow) * LD + fk;
   const float* sb0 = smem + BM * LD + (wn * WTN + frow) * LD + fk;
   constexpr int KO = BK / 8;
-  for (int step = 0; step < nsteps; ++step) {
-    const int cur = step & 1;
+  // one pipeline step on LDS buffer `cur`; `mid` runs between the two MFMA halves
+  auto step_body = [&](int cur, auto mid) {
     const float* sa = sa0 + cur * STAGE;
     const float* sb = sb0 + cur * STAGE;
     // fragments (4 k's per b128 read) are fetched one k-octet ahead of the MFMAs that consume them
@@ -164,10 +167,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
 #pragma unroll
         for (int j = 0; j < NI; ++j) bf[n][j] = *reinterpret_cast<const float4*>(sb + j * 32 * LD + (ko + 1) * 8);
       }
-      if (ko == KO / 2) {
-        lstore(cur ^ 1);
-        gload(step + 2);
-      }
+      if (ko == KO / 2) mid();
       __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (see conv_wgrad.hip)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -181,6 +181,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
       __builtin_amdgcn_sched_barrier(0);
     }
     __syncthreads();
+  };
+  const int nsteps2 = (nsteps + 1) & ~1;                       // steps come in (even, odd) pairs; a padded step adds zeros
+  for (int step = 0; step < nsteps2; step += 2) {
+    step_body(0, [&]() { lstore(1, regA1, regB1); gload(step + 3, regA1, regB1); });
+    step_body(1, [&]() { lstore(0, regA0, regB0); gload(step + 4, regA0, regB0); });
   }
 
   // ---- epilogue: acc reg r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]

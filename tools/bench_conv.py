@@ -31,7 +31,10 @@ def run(fn, iters):
     ops.prof_reset()
     ms = sum(r[1] for r in recs) / iters
     fl = sum(r[2] for r in recs) / iters
-    names = sorted({r[0] for r in recs})
+    per = {}
+    for r in recs:
+        per[r[0]] = per.get(r[0], 0.0) + r[1] / iters
+    names = [f"{k}={v * 1e3:.1f}us" for k, v in sorted(per.items())]
     return ms, fl, names
 
 
@@ -57,7 +60,10 @@ def main():
         y, dx, dw = torch.empty_like(dy), torch.empty_like(x), torch.empty_like(w)
         nb = ops.conv2d_bwd_filter_workspace_bytes(B, H, W, Ci, Co, 5, s)
         ws = torch.empty(nb // 4 + 4, device="cuda") if nb else None
-        for op, fn in (("fwd", lambda: ops.conv2d_fwd(x, wT, y, 5, s)), ("dgrad", lambda: ops.conv2d_bwd_data(dy, w, dx, 5, s)),
+        nf, nd = ops.conv2d_splitk_workspace_bytes(False, B, H, W, Ci, Co, 5, s), ops.conv2d_splitk_workspace_bytes(True, B, H, W, Ci, Co, 5, s)
+        wsk = torch.empty(max(nf, nd) // 4 + 4, device="cuda")
+        ef, ed = ops.epilogue(ws=wsk if nf else None), ops.epilogue(ws=wsk if nd else None)     # split-K scratch as the engine passes it
+        for op, fn in (("fwd", lambda: ops.conv2d_fwd(x, wT, y, 5, s, ef)), ("dgrad", lambda: ops.conv2d_bwd_data(dy, w, dx, 5, s, ed)),
                        ("wgrad", lambda: ops.conv2d_bwd_filter(x, dy, dw, 5, s, 0.0, 1.0, ws))):
             ms, fl, names = run(fn, a.iters)
             tf = fl / (ms * 1e-3) / 1e12
