@@ -18,7 +18,7 @@ class Epilogue(C.Structure):
                 ("alpha", C.c_float), ("scale", C.c_float), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t)]
 
 
-EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH = 0, 1, 2, 3
+EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_AFFINE_LRELU = 0, 1, 2, 3, 4
 
 _p, _i, _f, _z, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
 
@@ -48,6 +48,7 @@ SIGNATURES = {
     "bg_bn_train_fwd": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _i, _f, _p, _z, _p]),
     "bg_bn_infer_fwd": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _f, _f, _p]),
     "bg_bn_train_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _z, _p]),
+    "bg_bn_fold_f32": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "bg_bn_stats_f32": (_i, [_p, _i, _i, _p, _p, _z, _p]),
     "bg_bn_finalize_f32": (_i, [_p, _i, _i, _p, _p, _p, _p, _f, _f, _i, _p]),
     "bg_bn_apply_f32": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _f, _p]),

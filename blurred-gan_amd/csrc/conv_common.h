@@ -126,6 +126,10 @@ __device__ inline void decode_row(const GatherParams& p, const GatherPhase& g, i
 }
 
 __device__ inline float apply_epilogue(const GatherParams& p, float v, size_t idx, int n) {
+  if (p.epi_mode == BG_EPI_AFFINE_LRELU) {             // folded inference BatchNorm + LeakyReLU
+    v = fmaf(v, p.ref[n], p.bias[n]);
+    return v > 0.f ? v : p.alpha * v;
+  }
   if (p.bias) v += p.bias[n];
   switch (p.epi_mode) {
     case BG_EPI_BIAS_LRELU:

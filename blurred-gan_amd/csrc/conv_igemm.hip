@@ -663,8 +663,9 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
   if (epi) {
     p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep;
     p.alpha = epi->alpha; p.scale = epi->scale;
-    BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_TANH, BG_ERR_UNSUPPORTED, "%s: epilogue mode %d", tag, epi->mode);
+    BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "%s: epilogue mode %d", tag, epi->mode);
     BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || epi->ref, BG_ERR_NULL, "%s: BG_EPI_MUL_GRAD needs ref", tag);
+    BG_REQUIRE(epi->mode != BG_EPI_AFFINE_LRELU || (epi->ref && epi->bias), BG_ERR_NULL, "%s: BG_EPI_AFFINE_LRELU needs ref (scale) and bias (shift)", tag);
   }
   const int Mmax = max_phase_m(p);
   BG_REQUIRE((size_t)p.B * p.Hd * p.Wd * (size_t)p.N < (1ull << 31) && (size_t)p.B * p.Hs * p.Ws * (size_t)p.Ck < (1ull << 31),

@@ -92,6 +92,29 @@ __global__ __launch_bounds__(kT) void gemm_tiled_kernel(const float* __restrict_
   }
 }
 
+// N == 1, transA: out[m] = sum_k A[k][m] * b[k]  (weight gradient of the critic's Dense(2048 -> 1): A = activations [B, 2048]).
+// Block = 64 columns x 16 k-lanes, LDS tree over the k-lanes; coalesced along m.
+__global__ __launch_bounds__(1024) void gemv_t_kernel(const float* __restrict__ A, const float* __restrict__ b, float* __restrict__ C,
+                                                      int M, int K, const float* __restrict__ bias, float beta, float scale) {
+  __shared__ float red[16][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int m = blockIdx.x * 64 + tx;
+  float acc = 0.f;
+  if (m < M)
+    for (int k = ty; k < K; k += 16) acc = fmaf(A[(size_t)k * M + m], b[k], acc);
+  red[ty][tx] = acc;
+  __syncthreads();
+  if (ty == 0 && m < M) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += red[i][tx];
+    float v = scale * s;
+    if (bias) v += bias[0];
+    if (beta != 0.f) v += beta * C[m];
+    C[m] = v;
+  }
+}
+
 // N == 1, no transposes: one wave per row (critic's Dense(2048 -> 1))
 __global__ __launch_bounds__(kT) void rowdot_kernel(const float* __restrict__ A, const float* __restrict__ w, float* __restrict__ C,
                                                     int M, int K, const float* __restrict__ bias, float beta, float scale) {
@@ -257,6 +280,16 @@ __global__ __launch_bounds__(kT) void bn_stats_final_kernel(const float* __restr
     moving_mean[c] = moving_mean[c] * momentum + mean * (1.f - momentum);
     moving_var[c] = moving_var[c] * momentum + vu * (1.f - momentum);
   }
+}
+
+__global__ __launch_bounds__(kT) void bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ mm, const float* __restrict__ mv, float eps, int C,
+                                                     float* scale, float* shift) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c >= C) return;
+  const float s = gamma[c] * (1.0f / sqrtf(mv[c] + eps));
+  scale[c] = s;
+  shift[c] = beta[c] - mm[c] * s;
 }
 
 // sums[q*C + c] = sum over blocks of partial[(b*2 + q)*C + c]   (one wave per channel)
@@ -544,6 +577,11 @@ int bg_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, 
     hipLaunchKernelGGL(rowdot_kernel, dim3(bg::cdiv(M, kT / 64)), dim3(kT), 0, L.s, A, Bm, C, M, K, bias, beta, scale);
     return L.done("rowdot_kernel");
   }
+  if (N == 1 && transA && K >= 64) {
+    bg::Launch L(stream, "dense_gemv_t", flops, 4.0 * M * K);
+    hipLaunchKernelGGL(gemv_t_kernel, dim3(bg::cdiv(M, 64)), dim3(1024), 0, L.s, A, Bm, C, M, K, bias, beta, scale);
+    return L.done("gemv_t_kernel");
+  }
   if ((size_t)M * N >= 4096 && K >= 8) {
     bg::Launch L(stream, "dense_gemm_tiled", flops, 0);
     hipLaunchKernelGGL(gemm_tiled_kernel, dim3(bg::cdiv(N, 64), bg::cdiv(M, 64)), dim3(kT), 0, L.s, A, Bm, C, M, N, K, transA, transB, bias, beta, scale);
@@ -650,6 +688,15 @@ int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, 
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M, C, gamma, save_mean, save_inv,
                      dgamma, dbeta, lrelu_alpha);
   return L.done("bn_bwd_apply_kernel");
+}
+
+int bg_bn_fold_f32(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps, int C,
+                   float* scale_out, float* shift_out, void* stream) {
+  BG_REQUIRE(gamma && beta && moving_mean && moving_var && scale_out && shift_out, BG_ERR_NULL, "bg_bn_fold_f32: null pointer");
+  BG_REQUIRE(C > 0, BG_ERR_BAD_SHAPE, "bg_bn_fold_f32: C=%d", C);
+  bg::Launch L(stream, "bn_fold", 0, 0);
+  hipLaunchKernelGGL(bn_fold_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, gamma, beta, moving_mean, moving_var, eps, C, scale_out, shift_out);
+  return L.done("bn_fold_kernel");
 }
 
 static int bn_partials(const char* fn, const float* x, int M, int C, float* partial, void* stream) {

@@ -16,7 +16,7 @@ import numpy as np
 import torch
 
 from . import dist, ops
-from ._lib import EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH
+from ._lib import EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_AFFINE_LRELU
 
 
 class Stage:
@@ -222,7 +222,17 @@ class Net:
                     geom = (False, B, st.in_shape[0], st.in_shape[1], st.in_shape[2], lin.filters, lin.k, lin.stride)
                 else:           # ConvT forward == data-gradient of the conv whose input side is this layer's output
                     geom = (True, B, st.out_shape[0], st.out_shape[1], lin.filters, st.in_shape[2], lin.k, lin.stride)
-                if st.bn is not None:
+                fold_bn = st.bn is not None and not training and bias is None
+                if fold_bn:
+                    # inference BatchNorm (generator inside the D-step) folded into the conv epilogue: no z, no BN pass
+                    C = st.out_shape[-1]
+                    sc = ctx.bn_sums(i, C)
+                    bn = st.bn
+                    ops.bn_fold(bn.vars["gamma"], bn.vars["beta"], bn.vars["moving_mean"], bn.vars["moving_variance"], bn.epsilon,
+                                sc[:C], sc[C:])
+                    epi = self._epi(*geom, EPI_AFFINE_LRELU, bias=sc[C:], ref=sc[:C], alpha=st.alpha)
+                    tgt = out
+                elif st.bn is not None:
                     epi = self._epi(*geom, EPI_NONE, bias=bias)
                 elif st.act == "lrelu":
                     epi = self._epi(*geom, EPI_BIAS_LRELU, bias=bias, keep=keep, alpha=st.alpha,
@@ -235,7 +245,7 @@ class Net:
                     ops.conv2d_fwd(xin, self.store.transposed_kernel(st.lin), tgt, st.lin.k, st.lin.stride, epi)
                 else:   # Conv2DTranspose forward == data-gradient of the conv with the same kernel array
                     ops.conv2d_bwd_data(xin, st.lin.vars["kernel"], tgt, st.lin.k, st.lin.stride, epi)
-            if st.bn is not None:
+            if st.bn is not None and not (st.kind != "dense" and not training and bias is None):
                 C = st.out_shape[-1]
                 M = tgt.numel() // C
                 bn = st.bn

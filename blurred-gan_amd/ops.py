@@ -8,7 +8,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import Epilogue, EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, check
+from ._lib import Epilogue, EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_AFFINE_LRELU, check
 
 LRELU_ALPHA = 0.3
 
@@ -179,6 +179,11 @@ def bn_train_bwd(dy, y, x, dx, M, Cc, gamma, save_mean, save_inv, dgamma, dbeta,
                                       _ptr(dgamma), _ptr(dbeta), lrelu_alpha, _ptr(ws), ws.numel() * ws.element_size(),
                                       _stream()), "bg_bn_train_bwd")
     return dx
+
+
+def bn_fold(gamma, beta, moving_mean, moving_var, eps, scale_out, shift_out):
+    check(_lib.load().bg_bn_fold_f32(_ptr(gamma), _ptr(beta), _ptr(moving_mean), _ptr(moving_var), eps, gamma.numel(), _ptr(scale_out),
+                                     _ptr(shift_out), _stream()), "bg_bn_fold_f32")
 
 
 def bn_stats(x, M, Cc, sums, ws):

@@ -81,7 +81,8 @@ typedef enum {
   BG_EPI_NONE = 0,        /* y = acc (+ bias)                                                   */
   BG_EPI_BIAS_LRELU = 1,  /* y = lrelu(acc + bias); then y *= keep ? scale : 0 when keep != NULL */
   BG_EPI_MUL_GRAD = 2,    /* y = acc * (ref > 0 ? 1 : alpha) [* keep ? scale : 0]               */
-  BG_EPI_TANH = 3         /* y = tanh(acc + bias)                                               */
+  BG_EPI_TANH = 3,        /* y = tanh(acc + bias)                                               */
+  BG_EPI_AFFINE_LRELU = 4 /* y = lrelu(acc * ref[c] + bias[c]): inference BatchNormalization folded (bg_bn_fold_f32), ref = per-channel scale */
 } bg_epi_mode;
 
 typedef struct {
@@ -136,6 +137,10 @@ int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, 
                     const float* gamma, const float* save_mean, const float* save_inv,
                     float* dgamma, float* dbeta, float lrelu_alpha, void* ws_d, size_t ws_bytes, void* stream);
 
+/* inference BatchNormalization as a per-channel affine: scale = gamma / sqrt(moving_var + eps), shift = beta - moving_mean * scale
+ * (feeds BG_EPI_AFFINE_LRELU so the generator's inference forward inside the D-step, wgan.py:135, needs no separate BN pass) */
+int bg_bn_fold_f32(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps, int C,
+                   float* scale_out, float* shift_out, void* stream);
 /* The same BatchNormalization in separable pieces, for data-parallel SyncBN: the per-channel sums are
  * all-reduced by the caller between the pieces.  sums_d = [2*C]: forward {sum x, sum x^2}; backward {sum dz, sum dz*xhat}
  * with dz = dy * lrelu'(y).  M_total = rows summed over all replicas. */
