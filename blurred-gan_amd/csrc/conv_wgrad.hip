@@ -28,6 +28,7 @@ struct WgradParams {
   float beta, scale; // applied only when ksplit == 1
   unsigned x_bytes, dy_bytes;
   unsigned mul_hw, sh_hw, mul_w, sh_w;   // magic-number division by Ho*Wo and Wo (dividends < 2^31)
+  int lg_w, lg_h, pow2;                  // log2(Wo), log2(Ho) when both are powers of two (pow2 = 1)
 };
 
 // floor(m / d) for m < 2^31 with host-computed (mul, sh): q = (m * mul) >> sh
@@ -36,7 +37,7 @@ __device__ inline int fastdiv(int m, unsigned mul, unsigned sh) { return (int)((
 // Main filter-gradient kernel (grid.y = tap): same pipeline as the forward kernel -- buffer loads with the
 // hardware range check doing the zero padding / tails, branch-free single-block loop body, one barrier per step:
 //   step s: MFMA(first half of chunk s) | ds_write chunk s+1 | issue loads of chunk s+2 | MFMA(second half) | barrier
-template <int BM, int BN, int BKP, int WAVES_M, int WAVES_N, int WAVES_K>
+template <int BM, int BN, int BKP, int WAVES_M, int WAVES_N, int WAVES_K, bool P2>
 __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p) {
   static_assert(WAVES_M * WAVES_N * WAVES_K == 4, "4 waves");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -114,7 +115,38 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
   }
   const int b_dstep = BKP * p.Co * 4;
 
+  // P2 (Ho, Wo powers of two -- every layer of the 64/128-pixel models): a chunk of BKP pixels starting at a multiple of
+  // BKP decomposes as (chunk origin: wave-uniform, kept in SGPRs) + (row inside the chunk: per-thread constant) with no
+  // carries, so the per-step bookkeeping is scalar and each load costs an add and two range checks, as in the forward kernel.
+  int t_oy[AP], t_ox[AP], t_r[AP];
+  unsigned t_off[AP];
+  if (P2) {
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int r = arow + i * RPP_A;
+      const int bb = r >> (p.lg_w + p.lg_h), oh = (r >> p.lg_w) & (p.Ho - 1), ow = r & (p.Wo - 1);
+      t_r[i] = r;
+      t_oy[i] = oh * p.s;
+      t_ox[i] = ow * p.s;
+      t_off[i] = (unsigned)(((bb * p.H + oh * p.s) * p.W + ow * p.s) * p.Ci * 4 + a_coloff);
+    }
+  }
+  int s_m0 = m_begin;                                       // chunk origin of the NEXT gload (wave-uniform)
+
   auto gload = [&](int) {     // loads the NEXT chunk in sequence (called once per step, in order)
+    if (P2) {
+      const int m0 = __builtin_amdgcn_readfirstlane(s_m0);
+      const int b0 = m0 >> (p.lg_w + p.lg_h), oh0 = (m0 >> p.lg_w) & (p.Ho - 1), ow0 = m0 & (p.Wo - 1);
+      const int yS = oh0 * p.s + dyk, xS = ow0 * p.s + dxk;
+      const unsigned offS = (unsigned)(((b0 * p.H + yS) * p.W + xS) * p.Ci * 4);
+      const int left = m_end - m0;                            // rows of this chunk inside the split
+#pragma unroll
+      for (int i = 0; i < AP; ++i) {
+        const bool ok = a_col_ok && t_r[i] < left && (unsigned)(t_oy[i] + yS) < (unsigned)p.H && (unsigned)(t_ox[i] + xS) < (unsigned)p.W;
+        regA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? t_off[i] + offS : kOob, 0, 0));
+      }
+      s_m0 = m0 + BKP;
+    } else {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const bool ok = a_col_ok && a_m[i] < m_end && (unsigned)(a_ohS[i] + dyk) < (unsigned)p.H &&
@@ -132,6 +164,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
       oh -= c2 ? HoS : 0;
       off += c2 ? (unsigned)corr_h : 0u;
       a_owS[i] = ow; a_ohS[i] = oh; a_off[i] = off;
+    }
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i) {
@@ -857,6 +890,9 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     };
     magic((unsigned)(p.Ho * p.Wo), &p.mul_hw, &p.sh_hw);
     magic((unsigned)p.Wo, &p.mul_w, &p.sh_w);
+    auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
+    p.lg_w = lg2(p.Wo); p.lg_h = lg2(p.Ho);
+    p.pow2 = ((1 << p.lg_w) == p.Wo && (1 << p.lg_h) == p.Ho) ? 1 : 0;
     p.x_bytes = (unsigned)((size_t)B * H * W * Cin * sizeof(float));
     p.dy_bytes = (unsigned)((size_t)p.M * Cout * sizeof(float));
   }
@@ -879,11 +915,17 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     bg::Launch L(stream, pl.mode >= 20 ? "conv_wgrad_mfma_thin_co" : (pl.mode >= 10 ? "conv_wgrad_mfma_thin_ci" : "conv_wgrad_mfma"), flops, 0);
     const dim3 grid1((unsigned)(grid.x * grid.y * grid.z));      // v3 / tg kernels decode (tile, tap, split) themselves
     switch (pl.mode) {
-      case 1: hipLaunchKernelGGL((conv_wgrad_v3_kernel<128, 128, 32, 2, 2, 1>), grid1, dim3(256), 0, L.s, p); break;
-      case 2: hipLaunchKernelGGL((conv_wgrad_v3_kernel<64, 64, 32, 2, 2, 1>), grid1, dim3(256), 0, L.s, p); break;
-      case 3: hipLaunchKernelGGL((conv_wgrad_v3_kernel<64, 32, 64, 2, 1, 2>), grid1, dim3(256), 0, L.s, p); break;
-      case 4: hipLaunchKernelGGL((conv_wgrad_v3_kernel<32, 64, 64, 1, 2, 2>), grid1, dim3(256), 0, L.s, p); break;
-      case 5: hipLaunchKernelGGL((conv_wgrad_v3_kernel<32, 32, 128, 1, 1, 4>), grid1, dim3(256), 0, L.s, p); break;
+#define BG_V3(BMv, BNv, BKv, WMv, WNv, WKv)                                                                               \
+  do {                                                                                                                   \
+    if (p.pow2) hipLaunchKernelGGL((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, true>), grid1, dim3(256), 0, L.s, p);  \
+    else hipLaunchKernelGGL((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, false>), grid1, dim3(256), 0, L.s, p);        \
+  } while (0)
+      case 1: BG_V3(128, 128, 32, 2, 2, 1); break;
+      case 2: BG_V3(64, 64, 32, 2, 2, 1); break;
+      case 3: BG_V3(64, 32, 64, 2, 1, 2); break;
+      case 4: BG_V3(32, 64, 64, 1, 2, 2); break;
+      case 5: BG_V3(32, 32, 128, 1, 1, 4); break;
+#undef BG_V3
       case 6: hipLaunchKernelGGL((conv_wgrad_tg_kernel<5, 64, 2, 2>), grid1, dim3(256), 0, L.s, p); break;
       case 7: hipLaunchKernelGGL((conv_wgrad_tg_kernel<5, 32, 1, 4>), grid1, dim3(256), 0, L.s, p); break;
       case 10: hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 64, 1, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
