@@ -74,6 +74,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-sample-batch", type=int, default=16)
+    ap.add_argument("--kernels-out", default=None, help="write the full per-kernel table (and one step's launch sequence) to this JSON file")
     args = ap.parse_args()
 
     from blurred_gan_amd import dist, ops, callbacks
@@ -154,6 +155,12 @@ def main():
         if kern:
             top = sorted(kern.items(), key=lambda kv: -kv[1][1])[:12]
             out["kernels_ms_per_step"] = {n: round(k[1] / 2, 4) for n, k in top}
+        if kern and args.kernels_out:
+            table = [{"kernel": n, "launches_per_step": k[0] / 2, "ms_per_step": round(k[1] / 2, 5),
+                      "tflops": round(k[2] / (k[1] * 1e-3) / 1e12, 2) if k[2] else None} for n, k in sorted(kern.items(), key=lambda kv: -kv[1][1])]
+            seq = [{"kernel": n, "us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 3)} for n, ms, fl, _ in recs[:len(recs) // 2]]
+            with open(args.kernels_out, "w") as f:
+                json.dump({"ms_per_step_sum": round(sum(k[1] for k in kern.values()) / 2, 4), "kernels": table, "sequence": seq}, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_sample_batch)
         print(json.dumps(out), flush=True)

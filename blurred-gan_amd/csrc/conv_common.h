@@ -32,6 +32,8 @@ struct GatherParams {
   unsigned a_bytes, w_bytes;   // operand sizes for the buffer descriptors of the MFMA kernel
   int nphase;
   int mtiles, xcd_swizzle;   // MFMA kernel: M tiles per phase, XCD-aware tile order on/off
+  int pos_major;       // M index order: 0 = (b, a, bx) image-major; 1 = (a, bx, b) position-major (small feature maps: the rows of
+                       // a tile then share their spatial position, so zero-padding taps are skipped for the whole tile)
   int ksplit;          // split-K factor of the MFMA kernel (1 = none); partial sums go to slab[split][B*Hd*Wd*N]
   float* slab;
   // epilogue
@@ -113,8 +115,9 @@ struct RowAnchor {
 __device__ inline void decode_row(const GatherParams& p, const GatherPhase& g, int m, int Mph, RowAnchor& r, int& dst) {
   if (m < Mph) {
     const int hw = g.Ha * g.Wa;
-    const int b = m / hw;
-    const int rem = m - b * hw;
+    int b, rem;
+    if (p.pos_major) { rem = m / p.B; b = m - rem * p.B; }
+    else { b = m / hw; rem = m - b * hw; }
     const int a = rem / g.Wa;
     const int bx = rem - a * g.Wa;
     r.b = b; r.ay = a * p.ss; r.ax = bx * p.ss;

@@ -46,6 +46,8 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
 
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
   __shared__ int rowdst[BM];
+  __shared__ unsigned tapmask;               // taps that are in range for at least one row of this tile
+  __shared__ int taplist[bg::kMaxTaps];
 
   const int phase = blockIdx.z % p.nphase, split = blockIdx.z / p.nphase;
   const GatherPhase& g = p.ph[phase];
@@ -91,9 +93,31 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
     bg::decode_row(p, g, m0 + tid, Mph, tmp, dst);
     rowdst[tid] = dst;
   }
+  // Taps whose source pixel is zero padding for EVERY row of the tile are dropped from the K loop (no loads, no MFMAs).
+  // With position-major rows (small feature maps) that removes the padding work altogether: about half of all steps on
+  // 4x4 maps, a quarter on 8x8.
+  if (tid == 0) tapmask = 0u;
+  __syncthreads();
+  {
+    unsigned bits = 0u;
+    for (int t = 0; t < g.ntaps; ++t) {
+      const int dy = bg::tap_dy(g.tap[t]), dx = bg::tap_dx(g.tap[t]);
+      bool any = false;
+#pragma unroll
+      for (int i = 0; i < AP; ++i)
+        any |= (unsigned)(a_y[i] + dy) < (unsigned)p.Hs && (unsigned)(a_x[i] + dx) < (unsigned)p.Ws;
+      bits |= any ? (1u << t) : 0u;
+    }
+    if (bits) atomicOr(&tapmask, bits);
+  }
+  __syncthreads();
+  const unsigned tmask = tapmask;
+  const int ntaps_c = __popc(tmask);
+  if (tid < g.ntaps && ((tmask >> tid) & 1u)) taplist[__popc(tmask & ((1u << tid) - 1u))] = g.tap[tid];
+  __syncthreads();
 
   const int kchunks = p.Ck / BK;
-  const int nsteps_all = g.ntaps * kchunks;
+  const int nsteps_all = ntaps_c * kchunks;
   const int s_begin = (int)((long)nsteps_all * split / p.ksplit);          // this workgroup's slice of the K steps
   const int nsteps = (int)((long)nsteps_all * (split + 1) / p.ksplit) - s_begin;
   float4 regA0[AP], regB0[BP], regA1[AP], regB1[BP];     // two staging register sets (global loads run 2 steps ahead of their LDS write)
@@ -107,7 +131,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
     const int step = s_begin + lstep;
     const bool live = lstep < nsteps;                         // padded step (odd counts): poisoned offsets load zeros
     const int tq = step / kchunks;
-    const int tp = g.tap[min(tq, g.ntaps - 1)];
+    const int tp = taplist[min(tq, ntaps_c - 1)];
     const int c0 = (step - tq * kchunks) * BK;
     const int dy = bg::tap_dy(tp), dx = bg::tap_dx(tp);
     const unsigned tapoff = (unsigned)(((dy * p.Ws + dx) * p.Ck + c0) * 4);
@@ -618,6 +642,13 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
   if (ks > 1 && !(epi && epi->splitk_ws && epi->splitk_ws_bytes >= ks * total * sizeof(float))) ks = 1;
   p.ksplit = ks;
   p.slab = ks > 1 ? static_cast<float*>(epi->splitk_ws) : nullptr;
+  {
+    static const int no_pm = getenv("BG_NO_POS_MAJOR") ? 1 : 0;
+    static const int pm_max = getenv("BG_POS_MAJOR_MAX") ? atoi(getenv("BG_POS_MAJOR_MAX")) : 64;
+    int maxpos = 0;
+    for (int i = 0; i < p.nphase; ++i) maxpos = std::max(maxpos, p.ph[i].Ha * p.ph[i].Wa);
+    p.pos_major = (!no_pm && maxpos <= pm_max && p.B >= BM && p.B % BM == 0) ? 1 : 0;
+  }
   p.mtiles = (int)bg::cdiv(Mmax, BM);
   static const int no_swz = getenv("BG_NO_XCD_SWIZZLE") ? 1 : 0;
   p.xcd_swizzle = !no_swz;

@@ -28,7 +28,7 @@ struct WgradParams {
   float beta, scale; // applied only when ksplit == 1
   unsigned x_bytes, dy_bytes;
   unsigned mul_hw, sh_hw, mul_w, sh_w;   // magic-number division by Ho*Wo and Wo (dividends < 2^31)
-  int lg_w, lg_h, pow2;                  // log2(Wo), log2(Ho) when both are powers of two (pow2 = 1)
+  int lg_w, lg_h, lg_b, pow2;            // log2(Wo), log2(Ho), log2(B); pow2 = 1: Ho, Wo powers of two; 2: + B, small map (position-major)
 };
 
 // floor(m / d) for m < 2^31 with host-computed (mul, sh): q = (m * mul) >> sh
@@ -37,7 +37,11 @@ __device__ inline int fastdiv(int m, unsigned mul, unsigned sh) { return (int)((
 // Main filter-gradient kernel (grid.y = tap): same pipeline as the forward kernel -- buffer loads with the
 // hardware range check doing the zero padding / tails, branch-free single-block loop body, one barrier per step:
 //   step s: MFMA(first half of chunk s) | ds_write chunk s+1 | issue loads of chunk s+2 | MFMA(second half) | barrier
-template <int BM, int BN, int BKP, int WAVES_M, int WAVES_N, int WAVES_K, bool P2>
+// P2: 0 = any geometry (incremental per-thread row state); 1 = Ho, Wo powers of two (scalar chunk origin + per-thread
+// constants); 2 = additionally B a power of two and a small feature map: pixels are visited position-major (all images at
+// one output position, then the next position), so a chunk is zero padding for the tap either entirely or not at all and
+// the all-padding chunks are skipped (no loads, no MFMAs) -- about half of the chunks on 4x4 maps.
+template <int BM, int BN, int BKP, int WAVES_M, int WAVES_N, int WAVES_K, int P2>
 __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p) {
   static_assert(WAVES_M * WAVES_N * WAVES_K == 4, "4 waves");
   constexpr int WTM = BM / WAVES_M, WTN = BN / WAVES_N;
@@ -120,7 +124,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
   // carries, so the per-step bookkeeping is scalar and each load costs an add and two range checks, as in the forward kernel.
   int t_oy[AP], t_ox[AP], t_r[AP];
   unsigned t_off[AP];
-  if (P2) {
+  if (P2 == 1) {
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const int r = arow + i * RPP_A;
@@ -131,10 +135,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
       t_off[i] = (unsigned)(((bb * p.H + oh * p.s) * p.W + ow * p.s) * p.Ci * 4 + a_coloff);
     }
   }
+  if (P2 == 2) {       // position-major: row r of a chunk = image (b0 + r) at the chunk's position
+#pragma unroll
+    for (int i = 0; i < AP; ++i) {
+      const int r = arow + i * RPP_A;
+      t_r[i] = r;
+      t_oy[i] = 0;
+      t_ox[i] = 0;
+      t_off[i] = (unsigned)(r * p.H * p.W * p.Ci * 4 + a_coloff);
+    }
+#pragma unroll
+    for (int i = 0; i < BP; ++i) b_off[i] = (unsigned)((brow + i * RPP_B) * HoWo * p.Co * 4 + b_coloff);
+  }
   int s_m0 = m_begin;                                       // chunk origin of the NEXT gload (wave-uniform)
+  // P2 == 2: is the chunk starting at logical pixel m0 inside the image for this workgroup's tap?
+  auto chunk_live = [&](int m0) {
+    const int pos = m0 >> p.lg_b;
+    const int oh = pos >> p.lg_w, ow = pos & (p.Wo - 1);
+    return m0 < m_end && (unsigned)(oh * p.s + dyk) < (unsigned)p.H && (unsigned)(ow * p.s + dxk) < (unsigned)p.W;
+  };
 
   auto gload = [&](int) {     // loads the NEXT chunk in sequence (called once per step, in order)
-    if (P2) {
+    if (P2 == 2) {
+      const int m0 = __builtin_amdgcn_readfirstlane(s_m0);
+      s_m0 = m0 + BKP;
+      if (chunk_live(m0)) {                                  // wave-uniform: dead chunks issue no loads at all
+        const int pos = m0 >> p.lg_b, b0 = m0 & (p.B - 1);
+        const int oh = pos >> p.lg_w, ow = pos & (p.Wo - 1);
+        const unsigned offS = (unsigned)(((b0 * p.H + oh * p.s + dyk) * p.W + ow * p.s + dxk) * p.Ci * 4);
+        const unsigned offY = (unsigned)((b0 * HoWo + pos) * p.Co * 4);
+        const int left = m_end - m0;
+#pragma unroll
+        for (int i = 0; i < AP; ++i)
+          regA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (a_col_ok && t_r[i] < left) ? t_off[i] + offS : kOob, 0, 0));
+#pragma unroll
+        for (int i = 0; i < BP; ++i)
+          regB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+              rsY, (b_col_ok && brow + i * RPP_B < left) ? b_off[i] + offY : kOob, 0, 0));
+      }
+      return;
+    }
+    if (P2 == 1) {
       const int m0 = __builtin_amdgcn_readfirstlane(s_m0);
       const int b0 = m0 >> (p.lg_w + p.lg_h), oh0 = (m0 >> p.lg_w) & (p.Ho - 1), ow0 = m0 & (p.Wo - 1);
       const int yS = oh0 * p.s + dyk, xS = ow0 * p.s + dxk;
@@ -206,6 +247,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
     const int cur = step & 1;
     const float* sa = sa0 + cur * STAGE;
     const float* sb = sb0 + cur * STAGE;
+    if (P2 == 2) {
+      // uniform skips: a dead chunk costs one barrier; its neighbours still get their ds_write / loads
+      const int mc = m_begin + step * BKP;
+      const bool live_cur = chunk_live(mc), live_next = chunk_live(mc + BKP);
+      if (!live_cur) {
+        if (live_next) lstore(cur ^ 1);
+        gload(step + 2);
+        __syncthreads();
+        continue;
+      }
+    }
     // Fragment groups are fetched one group ahead of the MFMAs that consume them (register double buffer); the
     // sched_barrier pins that order -- left alone, the scheduler sinks each ds_read to just before its MFMA and
     // the LDS latency is exposed once per k-pair.
@@ -226,14 +278,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
       const int c = grp & 1;
       if (grp + 1 < NG) fetch(c ^ 1, grp + 1);
       if (grp == NG / 2) {
-        lstore(cur ^ 1);
+        if (P2 != 2 || chunk_live(m_begin + (step + 1) * BKP)) lstore(cur ^ 1);
         gload(step + 2);
       }
-#ifndef BG_WGRAD_INTERLEAVE
       __builtin_amdgcn_sched_barrier(0);
-#else
-      if (grp != NG / 2) __builtin_amdgcn_sched_barrier(0);      // middle group: loader VALU may interleave with its MFMAs
-#endif
 #pragma unroll
       for (int q = 0; q < PF; ++q)
 #pragma unroll
@@ -893,6 +941,9 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     auto lg2 = [](int v) { int l = 0; while ((1 << l) < v) ++l; return l; };
     p.lg_w = lg2(p.Wo); p.lg_h = lg2(p.Ho);
     p.pow2 = ((1 << p.lg_w) == p.Wo && (1 << p.lg_h) == p.Ho) ? 1 : 0;
+    p.lg_b = lg2(B);
+    static const int no_pm = getenv("BG_NO_POS_MAJOR") ? 1 : 0;
+    if (p.pow2 && !no_pm && (1 << p.lg_b) == B && B >= 128 && p.Ho * p.Wo <= 16) p.pow2 = 2;   // 8x8: the same-channel stride of position-major rows costs more than the skipped chunks save
     p.x_bytes = (unsigned)((size_t)B * H * W * Cin * sizeof(float));
     p.dy_bytes = (unsigned)((size_t)p.M * Cout * sizeof(float));
   }
@@ -917,8 +968,9 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     switch (pl.mode) {
 #define BG_V3(BMv, BNv, BKv, WMv, WNv, WKv)                                                                               \
   do {                                                                                                                   \
-    if (p.pow2) hipLaunchKernelGGL((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, true>), grid1, dim3(256), 0, L.s, p);  \
-    else hipLaunchKernelGGL((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, false>), grid1, dim3(256), 0, L.s, p);        \
+    if (p.pow2 == 2) hipLaunchKernelGGL((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, 2>), grid1, dim3(256), 0, L.s, p);     \
+    else if (p.pow2 == 1) hipLaunchKernelGGL((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, 1>), grid1, dim3(256), 0, L.s, p); \
+    else hipLaunchKernelGGL((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, 0>), grid1, dim3(256), 0, L.s, p);        \
   } while (0)
       case 1: BG_V3(128, 128, 32, 2, 2, 1); break;
       case 2: BG_V3(64, 64, 32, 2, 2, 1); break;
