@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libbgan_hip.so")
+LIB_PATH = os.environ.get("BGAN_HIP_LIB") or os.path.join(HERE, "libbgan_hip.so")   # override: kernel experiments only
 
 
 class BgError(RuntimeError):

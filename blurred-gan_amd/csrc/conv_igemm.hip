@@ -123,16 +123,24 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   float4 regA0[AP], regB0[BP], regA1[AP], regB1[BP];     // two staging register sets (global loads run 2 steps ahead of their LDS write)
 
   // Software pipeline, one barrier per step, loop body branch-free (the scheduler slots the loader between MFMAs):
-  //   step s:  MFMA(first half of tile s) | ds_write tile s+1 (loaded during step s-2) | issue loads of tile s+3
-  //            | MFMA(second half of tile s) | barrier
-  // Loads therefore have two full steps (~2 x 1024 MFMA cycles) to return: enough for an L2 miss served by the
-  // Infinity Cache / HBM, which the weight-streaming small-M layers (K = 6400) hit on most steps.
-  auto gload = [&](int lstep, float4 (&rA)[AP], float4 (&rB)[BP]) {
-    const int step = s_begin + lstep;
-    const bool live = lstep < nsteps;                         // padded step (odd counts): poisoned offsets load zeros
-    const int tq = step / kchunks;
-    const int tp = taplist[min(tq, ntaps_c - 1)];
-    const int c0 = (step - tq * kchunks) * BK;
+  //   step s:  MFMA(k-octets 0..KO/2-1 of tile s) | ds_write tile s+1 (loaded during step s-2) | issue loads of tile s+3
+  //            | barrier | MFMA(remaining octets of tile s), with the first fragments of tile s+1 fetched underneath
+  // The barrier sits in the MIDDLE of the step: every fragment read of tile s has been issued before it (fragments run one
+  // octet ahead of their MFMAs), so after it tile s+1 is complete in LDS and its first fragments are read while the last
+  // MFMAs of tile s execute -- no LDS round trip is exposed after the barrier.
+  // Loads have two full steps (~2 x 1024 MFMA cycles) to return: enough for an L2 miss served by the Infinity Cache /
+  // HBM, which the weight-streaming small-M layers (K = 6400) hit on most steps.
+  int g_tq = s_begin / kchunks;                          // compact tap index / channel chunk of the NEXT gload (wave-uniform)
+  int g_kc = s_begin - g_tq * kchunks;
+  int g_tp = taplist[min(g_tq, ntaps_c - 1)];            // its packed tap, read one gload ahead of its use
+  int g_left = nsteps;                                   // steps still to load; <= 0: padded step, poisoned offsets load zeros
+  auto gload = [&](float4 (&rA)[AP], float4 (&rB)[BP]) {
+#if defined(BG_EXP) && (BG_EXP & 1)
+    if (g_left < 1000000) { --g_left; return; }
+#endif
+    const bool live = g_left > 0;
+    const int tp = g_tp;
+    const int c0 = g_kc * BK;
     const int dy = bg::tap_dy(tp), dx = bg::tap_dx(tp);
     const unsigned tapoff = (unsigned)(((dy * p.Ws + dx) * p.Ck + c0) * 4);
     const unsigned woff = (unsigned)((bg::tap_wi(tp) * p.N * p.Ck + c0) * 4);
@@ -144,8 +152,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
 #pragma unroll
     for (int i = 0; i < BP; ++i)
       rB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_off[i] == kOob || !live) ? kOob : b_off[i] + woff, 0, 0));
+    --g_left;
+    if (++g_kc == kchunks) {
+      g_kc = 0;
+      ++g_tq;
+      g_tp = taplist[min(g_tq, ntaps_c - 1)];
+    }
   };
   auto lstore = [&](int buf, const float4 (&rA)[AP], const float4 (&rB)[BP]) {
+#if defined(BG_EXP) && (BG_EXP & 2)
+    if (g_left < 1000000) return;
+#endif
     float* sa = smem + buf * STAGE;
     float* sb = sa + BM * LD;
 #pragma unroll
@@ -162,36 +179,43 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  gload(0, regA0, regB0);
-  gload(1, regA1, regB1);
+  gload(regA0, regB0);
+  gload(regA1, regB1);
   lstore(0, regA0, regB0);
-  gload(2, regA0, regB0);
+  gload(regA0, regB0);
   __syncthreads();
 
   const int frow = lane & 31, fk = (lane >> 5) * 4;
   const float* sa0 = smem + (wm * WTM + frow) * LD + fk;
   const float* sb0 = smem + BM * LD + (wn * WTN + frow) * LD + fk;
-  constexpr int KO = BK / 8;
-  // one pipeline step on LDS buffer `cur`; `mid` runs between the two MFMA halves
+  constexpr int KO = BK / 8;                  // k-octets per step (2 or 4: even, so the fragment slots line up across steps)
+  // fragments: 4 k's per b128 read, fetched one k-octet ahead of the MFMAs that consume them, across step boundaries
+  float4 af[2][MI], bf[2][NI];
+  auto fetch = [&](int slot, int buf, int ko) {
+#if defined(BG_EXP) && (BG_EXP & 8)
+    if (g_left < 1000000 && (buf | ko)) return;
+#endif
+    const float* sa = sa0 + buf * STAGE + ko * 8;
+    const float* sb = sb0 + buf * STAGE + ko * 8;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[slot][i] = *reinterpret_cast<const float4*>(sa + i * 32 * LD);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bf[slot][j] = *reinterpret_cast<const float4*>(sb + j * 32 * LD);
+  };
+  fetch(0, 0, 0);
+  // one pipeline step on LDS buffer `cur`; `mid` (ds_write of the next tile, loads of a later one) runs before the barrier
   auto step_body = [&](int cur, auto mid) {
-    const float* sa = sa0 + cur * STAGE;
-    const float* sb = sb0 + cur * STAGE;
-    // fragments (4 k's per b128 read) are fetched one k-octet ahead of the MFMAs that consume them
-    float4 af[2][MI], bf[2][NI];
-#pragma unroll
-    for (int i = 0; i < MI; ++i) af[0][i] = *reinterpret_cast<const float4*>(sa + i * 32 * LD);
-#pragma unroll
-    for (int j = 0; j < NI; ++j) bf[0][j] = *reinterpret_cast<const float4*>(sb + j * 32 * LD);
 #pragma unroll
     for (int ko = 0; ko < KO; ++ko) {
       const int c = ko & 1, n = c ^ 1;
-      if (ko + 1 < KO) {
-#pragma unroll
-        for (int i = 0; i < MI; ++i) af[n][i] = *reinterpret_cast<const float4*>(sa + i * 32 * LD + (ko + 1) * 8);
-#pragma unroll
-        for (int j = 0; j < NI; ++j) bf[n][j] = *reinterpret_cast<const float4*>(sb + j * 32 * LD + (ko + 1) * 8);
+      if (ko + 1 < KO) fetch(n, cur, ko + 1);
+      if (ko == KO / 2) {
+        mid();
+#if !(defined(BG_EXP) && (BG_EXP & 4))
+        __syncthreads();                      // tile `cur^1` complete; every read of tile `cur` was issued (and drained) before it
+#endif
       }
-      if (ko == KO / 2) mid();
+      if (ko + 1 == KO) fetch(n, cur ^ 1, 0);
       __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (see conv_wgrad.hip)
 #pragma unroll
       for (int i = 0; i < MI; ++i)
@@ -204,12 +228,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
         }
       __builtin_amdgcn_sched_barrier(0);
     }
-    __syncthreads();
   };
   const int nsteps2 = (nsteps + 1) & ~1;                       // steps come in (even, odd) pairs; a padded step adds zeros
   for (int step = 0; step < nsteps2; step += 2) {
-    step_body(0, [&]() { lstore(1, regA1, regB1); gload(step + 3, regA1, regB1); });
-    step_body(1, [&]() { lstore(0, regA0, regB0); gload(step + 4, regA0, regB0); });
+    step_body(0, [&]() { lstore(1, regA1, regB1); gload(regA1, regB1); });
+    step_body(1, [&]() { lstore(0, regA0, regB0); gload(regA0, regB0); });
   }
 
   // ---- epilogue: acc reg r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]

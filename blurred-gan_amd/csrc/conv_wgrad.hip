@@ -816,6 +816,46 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   *reinterpret_cast<float4*>(dw + e) = o;
 }
 
+// Few outputs, many slabs (the thin layers: 2400 outputs x 768 slabs): 16 float4 columns x 64 slab groups per block,
+// LDS tree over the groups (fixed order -> deterministic)
+__global__ __launch_bounds__(1024) void wgrad_reduce_tall_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int n,
+                                                                 int ksplit, float beta, float scale) {
+  __shared__ float4 red[64][16];
+  const int c = threadIdx.x & 15, zg = threadIdx.x >> 4;
+  const int e = (blockIdx.x * 16 + c) * 4;
+  float4 s0 = make_float4(0.f, 0.f, 0.f, 0.f), s1 = s0;
+  if (e < n) {
+    int z = zg;
+    for (; z + 64 < ksplit; z += 128) {                    // two independent loads in flight
+      const float4 v0 = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + e);
+      const float4 v1 = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 64) * n + e);
+      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+      s1.x += v1.x; s1.y += v1.y; s1.z += v1.z; s1.w += v1.w;
+    }
+    if (z < ksplit) {
+      const float4 v0 = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + e);
+      s0.x += v0.x; s0.y += v0.y; s0.z += v0.z; s0.w += v0.w;
+    }
+  }
+  red[zg][c] = make_float4(s0.x + s1.x, s0.y + s1.y, s0.z + s1.z, s0.w + s1.w);
+  __syncthreads();
+  for (int h = 32; h > 0; h >>= 1) {
+    if (zg < h) {
+      const float4 a = red[zg][c], b = red[zg + h][c];
+      red[zg][c] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+    }
+    __syncthreads();
+  }
+  if (zg != 0 || e >= n) return;
+  const float4 a = red[0][c];
+  float4 o = make_float4(scale * a.x, scale * a.y, scale * a.z, scale * a.w);
+  if (beta != 0.f) {
+    const float4 q = *reinterpret_cast<const float4*>(dw + e);
+    o.x += beta * q.x; o.y += beta * q.y; o.z += beta * q.z; o.w += beta * q.w;
+  }
+  *reinterpret_cast<float4*>(dw + e) = o;
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int n,
                                                                   int ksplit, float beta, float scale) {
   const int e = blockIdx.x * 256 + threadIdx.x;
@@ -992,7 +1032,10 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
   if (rc) return rc;
   if (pl.ksplit > 1) {
     bg::Launch L(stream, "conv_wgrad_reduce", 0, (double)(pl.ksplit + 1) * nout * 4);
-    if (nout % 4 == 0 && bg::aligned16(ws_d))
+    if (nout % 4 == 0 && bg::aligned16(ws_d) && pl.ksplit >= 64 && nout <= 65536)
+      hipLaunchKernelGGL(wgrad_reduce_tall_kernel, dim3(bg::cdiv(nout / 4, 16)), dim3(1024), 0, L.s, static_cast<const float*>(ws_d), dw,
+                         (int)nout, pl.ksplit, beta, scale);
+    else if (nout % 4 == 0 && bg::aligned16(ws_d))
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bg::cdiv(nout / 4, 64)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,
                          (int)nout, pl.ksplit, beta, scale);
     else

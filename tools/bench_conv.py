@@ -50,7 +50,7 @@ def main():
     print(f"{'layer':<20}{'op':<8}{'ms':>9}{'TFLOP/s':>10}{'%peak':>8}  kernels")
     tot = {}
     for name, H, W, Ci, Co, s in LAYERS[a.arch]:
-        if a.only and a.only not in name:
+        if a.only and not any(o in name for o in a.only.split(",")):
             continue
         Ho, Wo = -(-H // s), -(-W // s)
         x = torch.rand(B, H, W, Ci, device="cuda") - 0.5
