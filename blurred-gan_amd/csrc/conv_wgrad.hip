@@ -789,6 +789,112 @@ __global__ __launch_bounds__(256) void wgrad_direct_kernel(const WgradParams p) 
   else *q = acc;
 }
 
+// ------------------------------------------------------------------------------------------------
+// thin-Co filter gradient on MFMA (stride 1, k*Co <= 16, Ci = 16 or 32: the generator's last conv 32->3):
+// the (kw, co) pairs are the 16 MFMA columns and the contraction runs over the pixels of one input row,
+//   dW[kh][kw][ci][co] = sum_{b, y', x'} x[b][y'][x'][ci] * dy[b][y' - kh + pt][x' - kw + pl][co]
+//                     = sum_{b, y'}  X_row(b, y')^T [ci x x']  *  B_kh [x' x (kw,co)],   B_kh[x'][kw*Co+co] = dyrow[(x' + pl - kw)*Co + co]
+// so each x element is loaded once (registers, A layout of v_mfma_f32_16x16x4_f32) and re-used by the k kernel rows; the dy
+// rows of a block of image rows sit in LDS with a zero halo (out-of-image rows / columns read as 0, no branches).
+// One workgroup = blocks of kTcRows image rows, one input row per wave at a time; partial dW per workgroup -> slab.
+// MFMA-bound: 2*M*k*k*Ci*16 flop (15 of the 16 columns useful for RGB).
+// ------------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int kTcRows = 16, kTcHalo = 8;
+
+template <int MT, int K>     // Ci = 16 * MT, K = kernel size (rows of taps kept in accumulators)
+__global__ __launch_bounds__(256) void conv_wgrad_thin_co_kernel(const WgradParams p, int nblocks, int blocks_per_img) {
+  extern __shared__ __attribute__((aligned(16))) float tc_lds[];
+  const int W = p.W, H = p.H, Ci = 16 * MT, Co = p.Co;
+  const int RS = W * Co + 2 * kTcHalo;                       // dy row stride in LDS (zero halo on both sides)
+  const int nrows = kTcRows + K - 1;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  floatx4 acc[K][MT];
+#pragma unroll
+  for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[kh][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  // column n = kw*Co + co of the B operand reads dyrow[(x' + pl - kw)*Co + co]; unused columns read a halo zero
+  const int ncol = K * Co;
+  const int kw_n = li / Co, co_n = li - kw_n * Co;
+  const int b_base = li < ncol ? kTcHalo + (kq + p.pl - kw_n) * Co + co_n : 0;
+  const int b_step = li < ncol ? 4 * Co : 0;                 // per k-step of 4 pixels
+  const int ksteps = W / 4;
+
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int b = blk / blocks_per_img, y0 = (blk - b * blocks_per_img) * kTcRows;
+    __syncthreads();                                          // previous block's fragments consumed
+    // dy rows y0 - pt .. y0 + kTcRows - 1 + (K - 1 - pt), zero outside the image, zero halos
+    for (int idx = tid; idx < nrows * RS; idx += 256) {
+      const int r = idx / RS, c = idx - r * RS;
+      const int oy = y0 - (K - 1 - p.pt) + r, e = c - kTcHalo;
+      float v = 0.f;
+      if ((unsigned)oy < (unsigned)p.Ho && (unsigned)e < (unsigned)(W * Co)) v = p.DY[((size_t)b * p.Ho + oy) * W * Co + e];
+      tc_lds[idx] = v;
+    }
+    __syncthreads();
+    // this wave's work list: (row r = wave + 4*j, pixel group g of 32) flattened; the x registers of item it+1 are
+    // loaded while the MFMAs of item it run
+    const int groups = (ksteps + 7) / 8;
+    const int myrows = min(kTcRows, H - y0);
+    const int nitems = ((myrows - wave + 3) / 4) * groups;       // rows wave, wave+4, ... < myrows
+    const float* xblk = p.X + ((size_t)b * H + y0) * W * Ci + kq * Ci + li;
+    auto xload = [&](int it, float (&a)[8][MT]) {
+      const int j = it / groups, g = it - j * groups;
+      const float* xrow = xblk + (size_t)(wave + 4 * j) * W * Ci + (size_t)g * 32 * Ci;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) a[q][mt] = (it < nitems && g * 8 + q < ksteps) ? xrow[(size_t)q * 4 * Ci + mt * 16] : 0.f;
+    };
+    auto compute = [&](int it, const float (&a)[8][MT]) {
+      const int j = it / groups, g = it - j * groups;
+      const int r = wave + 4 * j;
+      // x row y' pairs with dy row y' - kh + pt = LDS row r + (K - 1) - kh
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const float* brow = tc_lds + (r + (K - 1) - kh) * RS + b_base + g * 8 * b_step;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float bv = brow[q * b_step];
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[kh][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[q][mt], bv, acc[kh][mt], 0, 0, 0);
+        }
+      }
+    };
+    float a0[8][MT], a1[8][MT];
+    xload(0, a0);
+    for (int it = 0; it < nitems; it += 2) {
+      xload(it + 1, a1);
+      compute(it, a0);
+      xload(it + 2, a0);
+      if (it + 1 < nitems) compute(it + 1, a1);
+    }
+  }
+  // cross-wave sum through LDS, then the slab in dW layout [kh][kw][ci][co]; reg r of lane l = D[ci = 4*(l>>4) + r][n = l&15]
+  __syncthreads();
+  float* red = tc_lds;                                       // [4 waves][K*MT*4][64]
+#pragma unroll
+  for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) red[((wave * K + kh) * MT * 4 + mt * 4 + rr) * 64 + lane] = acc[kh][mt][rr];
+  __syncthreads();
+  float* out = p.out + (size_t)blockIdx.x * K * K * Ci * Co;
+  for (int e = tid; e < K * MT * 4 * 64; e += 256) {
+    const int l = e & 63, slot = e >> 6;                      // slot = (kh*MT + mt)*4 + rr
+    const int rr = slot & 3, mt = (slot >> 2) % MT, kh = slot / (4 * MT);
+    const int n = l & 15;
+    if (n >= ncol) continue;
+    const float v = (red[(0 * K * MT * 4 + slot) * 64 + l] + red[(1 * K * MT * 4 + slot) * 64 + l]) +
+                    (red[(2 * K * MT * 4 + slot) * 64 + l] + red[(3 * K * MT * 4 + slot) * 64 + l]);
+    const int kw = n / Co, co = n - kw * Co, ci = mt * 16 + 4 * (l >> 4) + rr;
+    out[((size_t)(kh * K + kw) * Ci + ci) * Co + co] = v;
+  }
+}
+
 // dw = beta*dw + scale * sum_z slabs[z]; block = 64 float4 columns x 4 slab groups (LDS tree), so few-output layers
 // with many slabs still expose enough parallelism
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int n,
@@ -899,6 +1005,16 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
     pl.tiles_m = 1;
     pl.tiles_n = bg::cdiv(Co, bn);
     pl.taps_in_grid = 0;
+  } else if (thin_co && (Ci == 16 || Ci == 32) && (k == 5 || k == 3) && k * Co <= 16 && W % 4 == 0 && !getenv("BG_WGRAD_NO_TC")) {
+    // row-MFMA kernel: one slab per workgroup, workgroups loop over blocks of kTcRows image rows
+    pl.mode = 30;
+    pl.bkp = 4;
+    const long nblocks = (long)B * bg::cdiv(H, kTcRows);
+    pl.ksplit = (int)std::max<long>(2, std::min<long>(nblocks, 1024));   // >= 2: beta / scale are applied by the slab reduce
+    pl.chunk = (int)nblocks;
+    pl.tiles_m = pl.tiles_n = 1;
+    pl.taps_in_grid = 0;
+    return pl;
   } else if (thin_co) {
     const int gw = kk * Co <= 32 ? 32 : (kk * Co <= 96 ? 96 : 128);
     pl.bkp = 64;
@@ -1001,6 +1117,17 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     bg::Launch L(stream, "conv_wgrad_direct", flops, 0);
     hipLaunchKernelGGL(wgrad_direct_kernel, dim3(bg::cdiv(nout, 256), pl.ksplit), dim3(256), 0, L.s, p);
     rc = L.done("wgrad_direct_kernel");
+  } else if (pl.mode == 30) {
+    bg::Launch L(stream, "conv_wgrad_mfma_thin_co", flops, 0);
+    const int bpi = (int)bg::cdiv(H, kTcRows), nblocks = B * bpi;
+    const int mt = Cin / 16;
+    const size_t lds = std::max((size_t)(kTcRows + ksize - 1) * (W * Cout + 2 * kTcHalo), (size_t)4 * ksize * mt * 4 * 64) * sizeof(float);
+    BG_REQUIRE(lds <= 64 * 1024, BG_ERR_UNSUPPORTED, "bg_conv2d_bwd_filter: thin-Co row kernel needs %zu bytes of LDS", lds);
+    if (ksize == 5 && mt == 2) hipLaunchKernelGGL((conv_wgrad_thin_co_kernel<2, 5>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
+    else if (ksize == 5) hipLaunchKernelGGL((conv_wgrad_thin_co_kernel<1, 5>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
+    else if (mt == 2) hipLaunchKernelGGL((conv_wgrad_thin_co_kernel<2, 3>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
+    else hipLaunchKernelGGL((conv_wgrad_thin_co_kernel<1, 3>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
+    rc = L.done("conv_wgrad_thin_co_kernel");
   } else {
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.taps_in_grid == 1 ? ksize * ksize : (pl.taps_in_grid == 2 ? ksize : 1), pl.ksplit);
     bg::Launch L(stream, pl.mode >= 20 ? "conv_wgrad_mfma_thin_co" : (pl.mode >= 10 ? "conv_wgrad_mfma_thin_ci" : "conv_wgrad_mfma"), flops, 0);
