@@ -895,6 +895,108 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_co_kernel(const WgradPara
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// thin-Ci filter gradient on MFMA (k*Ci <= 16, Co a multiple of 16: the critic's first conv RGB -> 32, MNIST 1 -> 64):
+// the mirror image of the kernel above -- the (kw, ci) pairs are the 16 MFMA rows, the contraction runs over the
+// output pixels of one row, and because x is NHWC with <= 3 channels the A operand is a contiguous window of the x row:
+//   dW[kh][kw][ci][co] = sum_{b, oy, ox} xrow(b, oy*s + kh - pt)[(ox*s - pl)*Ci + (kw*Ci + ci)] * dy[b][oy][ox][co]
+// dy elements are loaded once into registers (B layout) and re-used by the k kernel rows; x rows sit in LDS with a zero halo.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTiHalo = 16;
+
+template <int NT, int K>     // Co = 16 * NT
+__global__ __launch_bounds__(256) void conv_wgrad_thin_ci_kernel(const WgradParams p, int nblocks, int blocks_per_img, int RB) {
+  extern __shared__ __attribute__((aligned(16))) float ti_lds[];
+  const int W = p.W, H = p.H, Ci = p.Ci, Co = 16 * NT, Ho = p.Ho, Wo = p.Wo, st = p.s;
+  const int RS = W * Ci + 2 * kTiHalo;
+  const int nrows = (RB - 1) * st + K;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  floatx4 acc[K][NT];
+#pragma unroll
+  for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) acc[kh][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+  const int nrow_used = K * Ci;                               // MFMA rows in use: i = kw*Ci + ci
+  const int a_base = li < nrow_used ? kTiHalo + (kq * st - p.pl) * Ci + li : 0;
+  const int a_step = li < nrow_used ? 4 * st * Ci : 0;       // per k-step of 4 output pixels
+  const int ksteps = Wo / 4;
+  const int groups = (ksteps + 7) / 8;
+
+  for (int blk = blockIdx.x; blk < nblocks; blk += gridDim.x) {
+    const int b = blk / blocks_per_img, oy0 = (blk - b * blocks_per_img) * RB;
+    __syncthreads();
+    // x rows oy0*s - pt .. , zero outside the image, zero halos
+    for (int idx = tid; idx < nrows * RS; idx += 256) {
+      const int r = idx / RS, c = idx - r * RS;
+      const int yy = oy0 * st - p.pt + r, e = c - kTiHalo;
+      float v = 0.f;
+      if ((unsigned)yy < (unsigned)H && (unsigned)e < (unsigned)(W * Ci)) v = p.X[((size_t)b * H + yy) * W * Ci + e];
+      ti_lds[idx] = v;
+    }
+    __syncthreads();
+    const int myrows = min(RB, Ho - oy0);
+    const int nitems = ((myrows - wave + 3) / 4) * groups;
+    const float* dyblk = p.DY + ((size_t)b * Ho + oy0) * Wo * Co + kq * Co + li;
+    auto yload = [&](int it, float (&bv)[8][NT]) {
+      const int j = it / groups, g = it - j * groups;
+      const float* dyrow = dyblk + (size_t)(wave + 4 * j) * Wo * Co + (size_t)g * 32 * Co;
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) bv[q][nt] = (it < nitems && g * 8 + q < ksteps) ? dyrow[(size_t)q * 4 * Co + nt * 16] : 0.f;
+    };
+    auto compute = [&](int it, const float (&bv)[8][NT]) {
+      const int j = it / groups, g = it - j * groups;
+      const int r = wave + 4 * j;
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) {
+        const float* arow = ti_lds + (r * st + kh) * RS + a_base + g * 8 * a_step;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float av = arow[q * a_step];
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[kh][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[q][nt], acc[kh][nt], 0, 0, 0);
+        }
+      }
+    };
+    float b0[8][NT], b1[8][NT];
+    yload(0, b0);
+    for (int it = 0; it < nitems; it += 2) {
+      yload(it + 1, b1);
+      compute(it, b0);
+      yload(it + 2, b0);
+      if (it + 1 < nitems) compute(it + 1, b1);
+    }
+  }
+  // cross-wave sum through LDS in wave order (deterministic); reg rr of lane l = D[i = 4*(l>>4) + rr][j = l&15]
+  float* red = ti_lds;                                       // [K*NT*4][64]
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            float* q = red + ((kh * NT + nt) * 4 + rr) * 64 + lane;
+            *q = (w == 0 ? 0.f : *q) + acc[kh][nt][rr];
+          }
+    }
+  }
+  __syncthreads();
+  float* out = p.out + (size_t)blockIdx.x * K * K * Ci * Co;
+  for (int e = tid; e < K * NT * 4 * 64; e += 256) {
+    const int l = e & 63, slot = e >> 6;                      // slot = (kh*NT + nt)*4 + rr
+    const int rr = slot & 3, nt = (slot >> 2) % NT, kh = slot / (4 * NT);
+    const int i = 4 * (l >> 4) + rr;
+    if (i >= nrow_used) continue;
+    const int kw = i / Ci, ci = i - kw * Ci;
+    out[((size_t)(kh * K + kw) * Ci + ci) * Co + nt * 16 + (l & 15)] = red[e];
+  }
+}
+
 // dw = beta*dw + scale * sum_z slabs[z]; block = 64 float4 columns x 4 slab groups (LDS tree), so few-output layers
 // with many slabs still expose enough parallelism
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int n,
@@ -994,6 +1096,17 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
     long chunk = std::max(256L, (M + want - 1) / want);
     pl.chunk = (int)chunk;
     pl.ksplit = (int)((M + chunk - 1) / chunk);
+    return pl;
+  }
+  if (thin_ci && k * Ci <= 16 && (k == 5 || k == 3) && (Co == 16 || Co == 32 || Co == 64) && Wo % 4 == 0 && !getenv("BG_WGRAD_NO_TC")) {
+    pl.mode = 31;                                             // row-MFMA kernel, one slab per workgroup
+    pl.bkp = 4;
+    const int rb = s == 2 ? 8 : 16;                          // output rows per block
+    const long nblocks = (long)B * bg::cdiv(Ho, rb);
+    pl.ksplit = (int)std::max<long>(2, std::min<long>(nblocks, 1024));
+    pl.chunk = (int)nblocks;
+    pl.tiles_m = pl.tiles_n = 1;
+    pl.taps_in_grid = 0;
     return pl;
   }
   if (thin_ci) {
@@ -1117,6 +1230,18 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     bg::Launch L(stream, "conv_wgrad_direct", flops, 0);
     hipLaunchKernelGGL(wgrad_direct_kernel, dim3(bg::cdiv(nout, 256), pl.ksplit), dim3(256), 0, L.s, p);
     rc = L.done("wgrad_direct_kernel");
+  } else if (pl.mode == 31) {
+    bg::Launch L(stream, "conv_wgrad_mfma_thin_ci", flops, 0);
+    const int rb = stride == 2 ? 8 : 16;
+    const int bpi = (int)bg::cdiv(p.Ho, rb), nblocks = B * bpi;
+    const int nt = Cout / 16;
+    const size_t lds = std::max((size_t)((rb - 1) * stride + ksize) * (W * Cin + 2 * kTiHalo), (size_t)ksize * nt * 4 * 64) * sizeof(float);
+    BG_REQUIRE(lds <= 64 * 1024, BG_ERR_UNSUPPORTED, "bg_conv2d_bwd_filter: thin-Ci row kernel needs %zu bytes of LDS", lds);
+#define BG_TI(NTv, Kv) hipLaunchKernelGGL((conv_wgrad_thin_ci_kernel<NTv, Kv>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi, rb)
+    if (ksize == 5) { if (nt == 1) BG_TI(1, 5); else if (nt == 2) BG_TI(2, 5); else BG_TI(4, 5); }
+    else { if (nt == 1) BG_TI(1, 3); else if (nt == 2) BG_TI(2, 3); else BG_TI(4, 3); }
+#undef BG_TI
+    rc = L.done("conv_wgrad_thin_ci_kernel");
   } else if (pl.mode == 30) {
     bg::Launch L(stream, "conv_wgrad_mfma_thin_co", flops, 0);
     const int bpi = (int)bg::cdiv(H, kTcRows), nblocks = B * bpi;

@@ -17,6 +17,7 @@ CASES = [
     (2, 16, 16, 3, 32, 2), (2, 28, 28, 1, 64, 2), (2, 16, 16, 32, 3, 1), (2, 14, 14, 64, 1, 2), (2, 12, 12, 8, 4, 2),
     (2, 6, 6, 4, 8, 1), (1, 32, 32, 64, 32, 2), (9, 4, 4, 512, 512, 1),
     (3, 20, 12, 16, 3, 1), (2, 40, 16, 32, 2, 1),          # thin-Co row kernels: Ci 16 / 32, ragged row blocks
+    (3, 24, 24, 1, 64, 2), (2, 18, 16, 3, 16, 1), (2, 36, 32, 2, 32, 2),   # thin-Ci row kernels: Co 64 / 16 / 32, ragged row blocks
 ]
 
 
