@@ -135,9 +135,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   int g_tp = taplist[min(g_tq, ntaps_c - 1)];            // its packed tap, read one gload ahead of its use
   int g_left = nsteps;                                   // steps still to load; <= 0: padded step, poisoned offsets load zeros
   auto gload = [&](float4 (&rA)[AP], float4 (&rB)[BP]) {
-#if defined(BG_EXP) && (BG_EXP & 1)
-    if (g_left < 1000000) { --g_left; return; }
-#endif
     const bool live = g_left > 0;
     const int tp = g_tp;
     const int c0 = g_kc * BK;
@@ -160,9 +157,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
     }
   };
   auto lstore = [&](int buf, const float4 (&rA)[AP], const float4 (&rB)[BP]) {
-#if defined(BG_EXP) && (BG_EXP & 2)
-    if (g_left < 1000000) return;
-#endif
     float* sa = smem + buf * STAGE;
     float* sb = sa + BM * LD;
 #pragma unroll
@@ -192,9 +186,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   // fragments: 4 k's per b128 read, fetched one k-octet ahead of the MFMAs that consume them, across step boundaries
   float4 af[2][MI], bf[2][NI];
   auto fetch = [&](int slot, int buf, int ko) {
-#if defined(BG_EXP) && (BG_EXP & 8)
-    if (g_left < 1000000 && (buf | ko)) return;
-#endif
     const float* sa = sa0 + buf * STAGE + ko * 8;
     const float* sb = sb0 + buf * STAGE + ko * 8;
 #pragma unroll
@@ -211,9 +202,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
       if (ko + 1 < KO) fetch(n, cur, ko + 1);
       if (ko == KO / 2) {
         mid();
-#if !(defined(BG_EXP) && (BG_EXP & 4))
         __syncthreads();                      // tile `cur^1` complete; every read of tile `cur` was issued (and drained) before it
-#endif
       }
       if (ko + 1 == KO) fetch(n, cur ^ 1, 0);
       __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (see conv_wgrad.hip)

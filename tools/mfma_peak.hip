@@ -43,6 +43,53 @@ __global__ __launch_bounds__(256) void mfma16_loop(float* out, int iters, float 
   if (s == 12345.678f) out[0] = s;
 }
 
+// Random operands (8 A and 8 B registers per lane, hashed from the lane id): the chip holds a lower clock on toggling data
+// than on constants, so THIS is the ceiling real kernels are measured against.
+__device__ inline float hash01(unsigned x) {
+  x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+  return (float)(x & 0xffffff) * (2.0f / 16777216.0f) - 1.0f;
+}
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma32_rand_loop(float* out, int iters) {
+  floatx16 acc[NACC];
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  float a[8], b[8];
+  const unsigned id = blockIdx.x * 256 + threadIdx.x;
+  for (int i = 0; i < 8; ++i) { a[i] = hash01(id * 16 + i); b[i] = hash01(id * 16 + 8 + i); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u], b[(u + i) & 7], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[0] = s;
+}
+
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma16_rand_loop(float* out, int iters) {
+  floatx4 acc[NACC];
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 4; ++r) acc[i][r] = 0.f;
+  float a[8], b[8];
+  const unsigned id = blockIdx.x * 256 + threadIdx.x;
+  for (int i = 0; i < 8; ++i) { a[i] = hash01(id * 16 + i); b[i] = hash01(id * 16 + 8 + i); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[(u + i) & 7], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 4; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[0] = s;
+}
+
 template <typename F>
 static void run(const char* name, F launch, double flop_per_wg_iter, int wgs, int iters) {
   hipEvent_t e0, e1;
@@ -79,5 +126,15 @@ int main() {
       4.0 * 4 * 1 * 2.0 * 32 * 32 * 2, 1024, iters);
   run("16x16x4 f32, 4 acc/wave", [&](int g, int it) { hipLaunchKernelGGL(mfma16_loop<4>, dim3(g), dim3(256), 0, 0, out, it, 1.f, 2.f); },
       4.0 * 4 * 4 * 2.0 * 16 * 16 * 4, 1024, iters);
+  run("32x32x2 f32 RANDOM, 1 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma32_rand_loop<1>, dim3(g), dim3(256), 0, 0, out, it); },
+      4.0 * 8 * 1 * 2.0 * 32 * 32 * 2, 1024, iters / 2);
+  run("32x32x2 f32 RANDOM, 4 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma32_rand_loop<4>, dim3(g), dim3(256), 0, 0, out, it); },
+      4.0 * 8 * 4 * 2.0 * 32 * 32 * 2, 1024, iters / 8);
+  run("16x16x4 f32 RANDOM, 1 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma16_rand_loop<1>, dim3(g), dim3(256), 0, 0, out, it); },
+      4.0 * 8 * 1 * 2.0 * 16 * 16 * 4, 1024, iters);
+  run("16x16x4 f32 RANDOM, 4 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma16_rand_loop<4>, dim3(g), dim3(256), 0, 0, out, it); },
+      4.0 * 8 * 4 * 2.0 * 16 * 16 * 4, 1024, iters / 4);
+  run("16x16x4 f32 RANDOM, 8 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma16_rand_loop<8>, dim3(g), dim3(256), 0, 0, out, it); },
+      4.0 * 8 * 8 * 2.0 * 16 * 16 * 4, 1024, iters / 8);
   return 0;
 }
