@@ -154,4 +154,31 @@ __device__ inline float apply_epilogue(const GatherParams& p, float v, size_t id
   return v;
 }
 
+// same, with the per-column operands (bias, folded BatchNorm scale) already in registers
+__device__ inline float apply_epilogue_pre(const GatherParams& p, float v, size_t idx, float bias_n, float mul_n) {
+  if (p.epi_mode == BG_EPI_AFFINE_LRELU) {
+    v = fmaf(v, mul_n, bias_n);
+    return v > 0.f ? v : p.alpha * v;
+  }
+  v += bias_n;
+  switch (p.epi_mode) {
+    case BG_EPI_BIAS_LRELU:
+      v = v > 0.f ? v : p.alpha * v;
+      if (p.keep) v = p.keep[idx] ? v * p.scale : 0.f;
+      break;
+    case BG_EPI_MUL_GRAD: {
+      float f = p.ref[idx] > 0.f ? 1.f : p.alpha;
+      if (p.keep) f = p.keep[idx] ? f * p.scale : 0.f;
+      v *= f;
+      break;
+    }
+    case BG_EPI_TANH:
+      v = tanhf(v);
+      break;
+    default:
+      break;
+  }
+  return v;
+}
+
 }  // namespace bg

@@ -46,7 +46,6 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
 
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
   __shared__ int rowdst[BM];
-  __shared__ unsigned tapmask;               // taps that are in range for at least one row of this tile
   __shared__ int taplist[bg::kMaxTaps];
 
   const int phase = blockIdx.z % p.nphase, split = blockIdx.z / p.nphase;
@@ -94,24 +93,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
     rowdst[tid] = dst;
   }
   // Taps whose source pixel is zero padding for EVERY row of the tile are dropped from the K loop (no loads, no MFMAs).
-  // With position-major rows (small feature maps) that removes the padding work altogether: about half of all steps on
-  // 4x4 maps, a quarter on 8x8.
-  if (tid == 0) tapmask = 0u;
-  __syncthreads();
-  {
+  // Only position-major tiles can lose taps (all their rows sit at ONE output position; a pixel-major tile spans whole image
+  // rows, where every tap is in range for some pixel), and there the mask follows from any one row: no exchange needed.
+  unsigned tmask = g.ntaps >= 32 ? 0xffffffffu : ((1u << g.ntaps) - 1u);
+  if (p.pos_major) {
     unsigned bits = 0u;
     for (int t = 0; t < g.ntaps; ++t) {
       const int dy = bg::tap_dy(g.tap[t]), dx = bg::tap_dx(g.tap[t]);
-      bool any = false;
-#pragma unroll
-      for (int i = 0; i < AP; ++i)
-        any |= (unsigned)(a_y[i] + dy) < (unsigned)p.Hs && (unsigned)(a_x[i] + dx) < (unsigned)p.Ws;
-      bits |= any ? (1u << t) : 0u;
+      bits |= ((unsigned)(a_y[0] + dy) < (unsigned)p.Hs && (unsigned)(a_x[0] + dx) < (unsigned)p.Ws) ? (1u << t) : 0u;
     }
-    if (bits) atomicOr(&tapmask, bits);
+    tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)bits);
   }
-  __syncthreads();
-  const unsigned tmask = tapmask;
   const int ntaps_c = __popc(tmask);
   if (tid < g.ntaps && ((tmask >> tid) & 1u)) taplist[__popc(tmask & ((1u << tid) - 1u))] = g.tap[tid];
   __syncthreads();
@@ -175,6 +167,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
 
   gload(regA0, regB0);
   gload(regA1, regB1);
+  // per-column epilogue operands are fetched now, under the first tile loads, not after the last MFMA
+  float e_bias[NI], e_mul[NI];
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int n = n0 + wn * WTN + j * 32 + (lane & 31);
+    e_bias[j] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    e_mul[j] = (p.epi_mode == BG_EPI_AFFINE_LRELU && n < p.N) ? p.ref[n] : 1.f;
+  }
   lstore(0, regA0, regB0);
   gload(regA0, regB0);
   __syncthreads();
@@ -238,7 +238,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
         if (dst >= 0 && n < p.N) {
           const size_t idx = (size_t)dst * p.N + n;
           if (p.ksplit > 1) p.slab[(size_t)split * ((size_t)p.B * p.Hd * p.Wd * p.N) + idx] = acc[i][j][r];
-          else p.C[idx] = bg::apply_epilogue(p, acc[i][j][r], idx, n);
+          else p.C[idx] = bg::apply_epilogue_pre(p, acc[i][j][r], idx, e_bias[j], e_mul[j]);
         }
       }
     }
