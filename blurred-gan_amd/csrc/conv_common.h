@@ -128,7 +128,9 @@ __device__ inline void decode_row(const GatherParams& p, const GatherPhase& g, i
   }
 }
 
-__device__ inline float apply_epilogue(const GatherParams& p, float v, size_t idx, int n) {
+// P: any parameter block with the epilogue fields (epi_mode, bias, ref, keep, alpha, scale)
+template <class P>
+__device__ inline float apply_epilogue(const P& p, float v, size_t idx, int n) {
   if (p.epi_mode == BG_EPI_AFFINE_LRELU) {             // folded inference BatchNorm + LeakyReLU
     v = fmaf(v, p.ref[n], p.bias[n]);
     return v > 0.f ? v : p.alpha * v;
@@ -180,5 +182,9 @@ __device__ inline float apply_epilogue_pre(const GatherParams& p, float v, size_
   }
   return v;
 }
+
+// conv_rows.hip: row-MFMA kernel for thin-N forward (stride 1) / data gradient; *taken = 0 when the shape is not covered
+int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B, int H, int W, int Cin, int Cout, int k, int s,
+                  const bg_epilogue* epi, void* stream, int* taken);
 
 }  // namespace bg

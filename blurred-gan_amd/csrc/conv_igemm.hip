@@ -853,6 +853,9 @@ int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int
                   int stride, const bg_epilogue* epi, void* stream) {
   int rc = check_conv_args("bg_conv2d_fwd", x, wT_d, y, B, H, W, Cin, Cout, ksize, stride);
   if (rc) return rc;
+  int taken = 0;
+  rc = bg::try_conv_rows(0, x, wT_d, y, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
+  if (rc || taken) return rc;
   GatherParams p;
   memset(&p, 0, sizeof p);
   bg::make_fwd_params(p, B, H, W, Cin, Cout, ksize, stride);
@@ -864,6 +867,9 @@ int bg_conv2d_bwd_data(const float* dy, const float* w_d, float* dx, int B, int 
                        int stride, const bg_epilogue* epi, void* stream) {
   int rc = check_conv_args("bg_conv2d_bwd_data", dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride);
   if (rc) return rc;
+  int taken = 0;
+  rc = bg::try_conv_rows(1, dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
+  if (rc || taken) return rc;
   GatherParams p;
   memset(&p, 0, sizeof p);
   bg::make_bwd_data_params(p, B, H, W, Cin, Cout, ksize, stride);

@@ -1,0 +1,243 @@
+// Row-MFMA kernels for the thin ends of the networks (3-channel images on one side of the conv):
+// the generator's last conv 32->3 (forward) and the data gradient of the critic's first conv RGB->32
+// (reference demo_celeba.py:117-119 / :62-66; wgan.py:140,166,244 for the gradients).  SURVEY.md 8a rows T1, T2.
+//
+// Both are the same contraction in "scatter form": every input row iy (pixels x Ck channels, Ck = 16/32/64) is multiplied
+// ONCE by the k weight panels  B_kh[c][(kw, n)]  (n = the <= 3 thin channels, k*n <= 16 MFMA columns),
+//      P_kh[ix][(kw, n)] = sum_c in[iy][ix][c] * w(kh, kw)[n][c]
+// and P_kh lands in output row  y = iy*s + kh - pt;  along the row  out[y][x][n] = sum_{kw : x = ix*s + kw - pl} P[ix][(kw, n)].
+//   * data gradient of a stride-s conv: exactly this with the kernel array as it lies in memory ([tap][ci][co]);
+//   * stride-1 forward conv: the same with the taps flipped (kh -> k-1-kh, kw -> k-1-kw) and the pads mirrored.
+// A wave owns 16 pixels of the row; the input row is read once (coalesced float4 -> LDS -> A fragments of
+// v_mfma_f32_16x16x4_f32, loads two rows ahead), the k*Ck/4 weight fragments stay in registers for the whole kernel, and the k
+// output rows in flight live in k accumulators that shift down by s places after every input row.
+// A finished row goes through LDS once for the kw shift-add and leaves as contiguous stores with the fused epilogue.
+// MFMA-bound (no padding of the thin dimension beyond 15 -> 16 columns): 2 * rows * W * Ck * k * 16 flop.
+#include "conv_common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <type_traits>
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+struct RowParams {
+  const float* A;    // input rows [B][Hi][Wi][Ck]
+  const float* Wt;   // weights [tap][N][Ck]
+  float* C;          // output [B][Ho][Wo][N]
+  int B, Hi, Wi, Ck, Ho, Wo, N;
+  int pt, pl, flip;  // y = iy*S + kh - pt, x = ix*S + kw - pl; tap = flip ? (K-1-kh)*K + (K-1-kw) : kh*K + kw
+  int R, strips;     // output rows per strip, strips per image
+  int wpr, ipw;      // waves per input row (Wi / 16), images per workgroup (4 / wpr)
+  int epi_mode;
+  const float* bias;
+  const float* ref;
+  const unsigned char* keep;
+  float alpha, scale;
+};
+
+__device__ inline int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
+
+template <int KS, int K, int S>     // Ck = 4*KS, K x K taps, stride S of the scatter
+__global__ __launch_bounds__(256) void conv_rows_scatter_kernel(const RowParams p) {
+  extern __shared__ __attribute__((aligned(16))) float row_lds[];
+  constexpr int AS = 4 * KS + 4;                             // A row stride in LDS: conflict-free b32 fragment reads, 16-B aligned rows
+  float* abuf = row_lds;                                     // [2][ipw * Wi][AS]   input rows r, r+1
+  float* pbuf = row_lds + 2 * 64 * AS;                       // [2][S][ipw * Wi][17] finished P tiles (ipw * Wi = 64 pixels)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int t = wave % p.wpr, img = wave / p.wpr;
+  const int strip = blockIdx.x % p.strips, bgrp = blockIdx.x / p.strips;
+  const int b = bgrp * p.ipw + img;
+  const bool img_ok = b < p.B;
+  const int Ck = 4 * KS, N = p.N;
+  const int y0 = strip * p.R, y1 = min(y0 + p.R, p.Ho);
+  const int iy_lo = -floordiv(-(y0 + p.pt - (K - 1)), S);          // ceil((y0 + pt - (K-1)) / S)
+  const int iy_hi = floordiv(y1 - 1 + p.pt, S);
+  const int nrows = iy_hi - iy_lo + 1;
+
+  // weight fragments B[k = c][j = kw*N + n], all K kernel rows, resident
+  float bw[K][KS];
+  {
+    const int kw = li / N, n = li - kw * N;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+      const int tap = p.flip ? (K - 1 - kh) * K + (K - 1 - kw) : kh * K + kw;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) bw[kh][ks] = li < K * N ? p.Wt[((size_t)tap * N + n) * Ck + 4 * ks + kq] : 0.f;
+    }
+  }
+  floatx4 acc[K];
+#pragma unroll
+  for (int i = 0; i < K; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
+
+  // Input rows travel global -> registers (coalesced float4, two rows ahead) -> LDS -> A fragments; a direct gather of the
+  // fragment layout from global (16 cache lines per wave instruction) cost as much as all the MFMAs.
+  constexpr int QPR = KS;                                    // float4 per pixel
+  constexpr int NQ = 64 * QPR / 256;                         // float4 per thread per row set (64 pixels x Ck)
+  static_assert(NQ >= 1, "Ck >= 16");
+  auto gload = [&](int r, float4 (&g)[NQ]) {
+    const int iy = iy_lo + r;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int f = tid + q * 256, pix = f / QPR, c4 = f - pix * QPR;        // pix = im * Wi + ix
+      const int im = pix / p.Wi, ix = pix - im * p.Wi;
+      const int bb = bgrp * p.ipw + im;
+      const bool ok = bb < p.B && r < nrows && (unsigned)iy < (unsigned)p.Hi;
+      g[q] = ok ? *reinterpret_cast<const float4*>(p.A + (((size_t)bb * p.Hi + iy) * p.Wi + ix) * Ck + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  };
+  auto lstore = [&](int buf, const float4 (&g)[NQ]) {
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) {
+      const int f = tid + q * 256, pix = f / QPR, c4 = f - pix * QPR;
+      *reinterpret_cast<float4*>(abuf + (size_t)buf * 64 * AS + pix * AS + c4 * 4) = g[q];
+    }
+  };
+  const float* afrag = abuf + ((size_t)img * p.Wi + 16 * t + li) * AS + kq;
+  // Row-independent part of the kw shift-add, per thread: output element e = (image, x, n) of a finished row sums the
+  // P columns (kw, n) of the input pixels ix = (x + pl - kw) / S that exist.  Offsets into one P buffer, -1 = no term.
+  constexpr int NE = 3;                                      // output elements per thread: ipw * Wo * N <= 4 * 64 * 3 = 768
+  constexpr int NTERM = (K + S - 1) / S;
+  int e_src[NE][NTERM];
+  long e_dst[NE];                                            // offset of (image, y = 0, x, n) in the output, -1 = none
+  int e_n[NE];
+  {
+    const int per_img = p.Wo * N;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      const int e = tid + q * 256;
+      const int im = e / per_img, rem = e - im * per_img;
+      const int x = rem / N, n = rem - x * N;
+      const int bb = bgrp * p.ipw + im;
+      const bool ok = e < p.ipw * per_img && bb < p.B;
+      e_dst[q] = ok ? ((long)bb * p.Ho * p.Wo + x) * N + n : -1;
+      e_n[q] = n;
+#pragma unroll
+      for (int i = 0; i < NTERM; ++i) {
+        const int kw = (x + p.pl) % S + i * S;
+        const int num = x + p.pl - kw, ix = num / S;
+        e_src[q][i] = (ok && kw < K && num >= 0 && ix < p.Wi) ? (im * p.Wi + ix) * 17 + kw * N + n : -1;
+      }
+    }
+  }
+  // finished output row y: P tile -> LDS (before the row's barrier), then kw shift-add, epilogue, contiguous stores (after it)
+  auto pwrite = [&](const floatx4& pacc, int slot) {
+    float* pb = pbuf + (size_t)slot * 64 * 17;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) pb[((size_t)img * p.Wi + 16 * t + 4 * kq + rr) * 17 + li] = pacc[rr];
+  };
+  auto pstore = [&](int slot, int y) {
+    const float* pb = pbuf + (size_t)slot * 64 * 17;
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {
+      if (e_dst[q] < 0) continue;
+      float v = 0.f;
+#pragma unroll
+      for (int i = 0; i < NTERM; ++i)
+        if (e_src[q][i] >= 0) v += pb[e_src[q][i]];
+      const size_t idx = (size_t)(e_dst[q] + (long)y * p.Wo * N);
+      p.C[idx] = bg::apply_epilogue(p, v, idx, e_n[q]);
+    }
+  };
+
+  // One input row per trip, one barrier per trip.  acc[kh] always belongs to output row iy*S + kh - pt of the CURRENT input
+  // row: after the row the S finished accumulators are flushed and the rest move down S places (a handful of register moves
+  // against K*KS MFMAs), which keeps the loop body small enough for the instruction cache.
+  //   trip r:  A fragments of row r <- LDS | row r+1 registers -> LDS, loads of row r+2 | MFMAs | P tiles -> LDS | barrier | stores
+  float4 g0[NQ], g1[NQ];
+  gload(0, g0);
+  gload(1, g1);
+  lstore(0, g0);
+  __syncthreads();
+  for (int r = 0; r < nrows; ++r) {
+    const int iy = iy_lo + r, cur = r & 1;
+    float a[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) a[ks] = afrag[(size_t)cur * 64 * AS + 4 * ks];
+    // registers alternate by row parity; the branch is uniform
+    if (cur == 0) { lstore(1, g1); gload(r + 2, g0); } else { lstore(0, g0); gload(r + 2, g1); }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)                          // kh innermost: K independent accumulator chains
+#pragma unroll
+      for (int kh = 0; kh < K; ++kh) acc[kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bw[kh][ks], acc[kh], 0, 0, 0);
+    bool fl[S];
+#pragma unroll
+    for (int kh = 0; kh < S; ++kh) {                         // rows that just received their last contribution
+      const int y = iy * S + kh - p.pt;
+      fl[kh] = y >= y0 && y < y1;
+      if (fl[kh]) pwrite(acc[kh], cur * S + kh);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kh = 0; kh < S; ++kh)
+      if (fl[kh]) pstore(cur * S + kh, iy * S + kh - p.pt);
+#pragma unroll
+    for (int i = 0; i < K; ++i) acc[i] = i + S < K ? acc[i + S] : floatx4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+
+template <int K, int S>
+int launch_rows(const RowParams& p, dim3 grid, size_t lds, hipStream_t s) {
+  switch (p.Ck) {
+    case 16: hipLaunchKernelGGL((conv_rows_scatter_kernel<4, K, S>), grid, dim3(256), lds, s, p); return 1;
+    case 32: hipLaunchKernelGGL((conv_rows_scatter_kernel<8, K, S>), grid, dim3(256), lds, s, p); return 1;
+    case 64: hipLaunchKernelGGL((conv_rows_scatter_kernel<16, K, S>), grid, dim3(256), lds, s, p); return 1;
+    default: return 0;
+  }
+}
+
+}  // namespace
+
+namespace bg {
+
+// Tries the row kernel for a thin-N problem; returns BG_OK + *taken = 1 when it ran, *taken = 0 when the shape is not covered.
+//   forward (bwd_data = 0): x [B,H,W,Cin] -> y [B,H,W,Cout], stride 1, weights wT [tap][Cout][Cin]
+//   data gradient (bwd_data = 1): dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin], weights w [tap][Cin][Cout]
+int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B, int H, int W, int Cin, int Cout, int k, int s,
+                  const bg_epilogue* epi, void* stream, int* taken) {
+  *taken = 0;
+  static const int off = getenv("BG_NO_ROWS") ? 1 : 0;
+  if (off || (k != 5 && k != 3)) return BG_OK;
+  RowParams p;
+  memset(&p, 0, sizeof p);
+  int Ho, Wo, pt, pl;
+  same_pads(H, k, s, &Ho, &pt);
+  same_pads(W, k, s, &Wo, &pl);
+  if (bwd_data) {
+    if (Cin * k > 16 || (Cout != 16 && Cout != 32 && Cout != 64)) return BG_OK;
+    p.Hi = Ho; p.Wi = Wo; p.Ck = Cout; p.Ho = H; p.Wo = W; p.N = Cin; p.pt = pt; p.pl = pl; p.flip = 0;
+  } else {
+    if (s != 1 || Cout * k > 16 || (Cin != 16 && Cin != 32 && Cin != 64)) return BG_OK;
+    p.Hi = H; p.Wi = W; p.Ck = Cin; p.Ho = H; p.Wo = W; p.N = Cout; p.pt = k - 1 - pt; p.pl = k - 1 - pl; p.flip = 1;
+  }
+  if (p.Wi != 16 && p.Wi != 32 && p.Wi != 64) return BG_OK;                           // a workgroup handles 64 pixels: 4 / 2 / 1 images
+  if ((size_t)B * p.Hi * p.Wi * p.Ck >= (1ull << 31) || (size_t)B * p.Ho * p.Wo * p.N >= (1ull << 31)) return BG_OK;
+  p.A = a; p.Wt = w; p.C = c; p.B = B;
+  static const int rows_r = getenv("BG_ROWS_R") ? atoi(getenv("BG_ROWS_R")) : 0;       // tuning aid
+  p.R = std::min(rows_r ? rows_r : (s == 1 ? 32 : 16), p.Ho);                        // measured: halo rows (k-1)/s per strip vs workgroups in flight
+  p.strips = (int)cdiv(p.Ho, p.R);
+  p.wpr = p.Wi / 16;
+  p.ipw = 4 / p.wpr;
+  p.epi_mode = BG_EPI_NONE; p.alpha = 0.3f; p.scale = 1.f;
+  if (epi) {
+    BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "conv rows: epilogue mode %d", epi->mode);
+    BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || epi->ref, BG_ERR_NULL, "conv rows: BG_EPI_MUL_GRAD needs ref");
+    BG_REQUIRE(epi->mode != BG_EPI_AFFINE_LRELU || (epi->ref && epi->bias), BG_ERR_NULL, "conv rows: BG_EPI_AFFINE_LRELU needs ref and bias");
+    p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep; p.alpha = epi->alpha; p.scale = epi->scale;
+  }
+  const dim3 grid((unsigned)(cdiv(B, p.ipw) * p.strips));
+  const size_t lds = ((size_t)2 * 64 * (p.Ck + 4) + (size_t)2 * s * 64 * 17) * sizeof(float);
+  const double flops = 2.0 * B * (double)H * W * Cin * Cout * k * k / (s * s);
+  Launch L(stream, bwd_data ? "conv_rows_dgrad" : "conv_rows_fwd", flops, 0);
+  int ok;
+  if (k == 5) ok = s == 2 ? launch_rows<5, 2>(p, grid, lds, L.s) : launch_rows<5, 1>(p, grid, lds, L.s);
+  else ok = s == 2 ? launch_rows<3, 2>(p, grid, lds, L.s) : launch_rows<3, 1>(p, grid, lds, L.s);
+  (void)ok;
+  *taken = 1;
+  return L.done("conv_rows_scatter_kernel");
+}
+
+}  // namespace bg
