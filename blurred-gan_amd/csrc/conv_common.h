@@ -187,4 +187,7 @@ __device__ inline float apply_epilogue_pre(const GatherParams& p, float v, size_
 int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B, int H, int W, int Cin, int Cout, int k, int s,
                   const bg_epilogue* epi, void* stream, int* taken);
 
+int try_conv_rows_gather(int bwd_data, const float* a, const float* w, float* c, int B, int H, int W, int Cin, int Cout, int k, int s,
+                         const bg_epilogue* epi, void* stream, int* taken);
+
 }  // namespace bg

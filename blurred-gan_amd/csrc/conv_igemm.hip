@@ -856,6 +856,8 @@ int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int
   int taken = 0;
   rc = bg::try_conv_rows(0, x, wT_d, y, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
   if (rc || taken) return rc;
+  rc = bg::try_conv_rows_gather(0, x, wT_d, y, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
+  if (rc || taken) return rc;
   GatherParams p;
   memset(&p, 0, sizeof p);
   bg::make_fwd_params(p, B, H, W, Cin, Cout, ksize, stride);
@@ -869,6 +871,8 @@ int bg_conv2d_bwd_data(const float* dy, const float* w_d, float* dx, int B, int 
   if (rc) return rc;
   int taken = 0;
   rc = bg::try_conv_rows(1, dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
+  if (rc || taken) return rc;
+  rc = bg::try_conv_rows_gather(1, dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
   if (rc || taken) return rc;
   GatherParams p;
   memset(&p, 0, sizeof p);

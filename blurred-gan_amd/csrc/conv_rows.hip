@@ -189,9 +189,179 @@ int launch_rows(const RowParams& p, dim3 grid, size_t lds, hipStream_t s) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Gather form, thin CONTRACTION side (<= 3 input channels: the critic's first conv RGB -> 32 forward, and the data gradient
+// of the generator's last conv): with NHWC and Ct <= 3 channels the k*Ct values under one kernel row are a contiguous window
+// of the input row, so the MFMA contraction index is i = kw*Ct + ci (<= 15, one k-step of 4 x 4), per kernel row kh:
+//   out[oy][ox][n] = sum_kh sum_i xrow(oy*s + kh - pt)[(ox*s - pl)*Ct + i] * w(kh, i)[n]
+// Input rows of a strip sit in LDS with a zero halo (they are tiny: W*Ct floats), the k*4*NT weight fragments stay in
+// registers, every wave computes whole output rows (TG tiles of 16 pixels x NT tiles of 16 channels) with no barrier inside
+// the strip.  The stride-1 data gradient is the same with flipped taps and mirrored pads.
+// MFMA-bound at 2 * B*Ho*Wo * N * 16*k flop, no recompute; HBM-bound on the output for the forward.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRgHalo = 16;
+
+struct RowGParams {
+  const float* A;    // input rows [B][Hi][Wi][Ct]
+  const float* Wt;   // weights [tap][N][Ct]
+  float* C;          // output [B][Ho][Wo][N]
+  int B, Hi, Wi, Ct, Ho, Wo, N;
+  int s, pt, pl, flip;
+  int R, strips;     // output rows per strip, strips per image
+  int epi_mode;
+  const float* bias;
+  const float* ref;
+  const unsigned char* keep;
+  float alpha, scale;
+};
+
+template <int TG, int NT, int K>     // TG pixel tiles per unit, N = 16 * NT, K x K taps
+__global__ __launch_bounds__(256) void conv_rows_gather_kernel(const RowGParams p) {
+  extern __shared__ __attribute__((aligned(16))) float xl[];       // [(R-1)*s + K][Wi*Ct + 2*halo]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int Ct = p.Ct, N = 16 * NT, st = p.s;
+  const int RS = p.Wi * Ct + 2 * kRgHalo;
+  const int strip = blockIdx.x % p.strips, b = blockIdx.x / p.strips;
+  const int oy0 = strip * p.R, rows = min(p.R, p.Ho - oy0);
+  const int nrows_in = (rows - 1) * st + K;
+
+  // weight fragments B[k = i][j = n]: i = 4*ks + kq = kw*Ct + ci
+  float bw[K][4][NT];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    const int i = 4 * ks + kq, kw = i / Ct, ci = i - kw * Ct;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+      const int tap = p.flip ? (K - 1 - kh) * K + (K - 1 - kw) : kh * K + kw;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) bw[kh][ks][nt] = i < K * Ct ? p.Wt[((size_t)tap * N + nt * 16 + li) * Ct + ci] : 0.f;
+    }
+  }
+  // stage the strip's input rows (zero outside the image, zero halos: every word the fragments can touch is initialised)
+  const int RL = p.Wi * Ct;                                  // floats per input row
+  if ((RL & 3) == 0) {
+    const int q4 = RS / 4;                                   // float4 per LDS row (halo 16 and RL are multiples of 4)
+    for (int idx = tid; idx < nrows_in * q4; idx += 256) {
+      const int r = idx / q4, c4 = idx - r * q4;
+      const int iy = oy0 * st - p.pt + r, e = c4 * 4 - kRgHalo;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)e < (unsigned)RL) v = *reinterpret_cast<const float4*>(p.A + ((size_t)b * p.Hi + iy) * RL + e);
+      *reinterpret_cast<float4*>(xl + (size_t)r * RS + c4 * 4) = v;
+    }
+  } else {
+    for (int idx = tid; idx < nrows_in * RS; idx += 256) {
+      const int r = idx / RS, c = idx - r * RS;
+      const int iy = oy0 * st - p.pt + r, e = c - kRgHalo;
+      float v = 0.f;
+      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)e < (unsigned)RL) v = p.A[((size_t)b * p.Hi + iy) * RL + e];
+      xl[idx] = v;
+    }
+  }
+  __syncthreads();
+
+  const int groups = p.Wo / (16 * TG);                       // units per output row
+  const int nunits = rows * groups;
+  for (int u = wave; u < nunits; u += 4) {
+    const int r = u / groups, g = u - r * groups;
+    const int oy = oy0 + r, ox0 = g * 16 * TG;
+    floatx4 acc[TG][NT];
+#pragma unroll
+    for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[tg][nt] = floatx4{0.f, 0.f, 0.f, 0.f};
+    // A[m = ox][k = i] = xrow[(ox*s - pl)*Ct + i]
+    const float* abase = xl + (size_t)(r * st) * RS + kRgHalo + ((ox0 + li) * st - p.pl) * Ct + kq;
+#pragma unroll
+    for (int kh = 0; kh < K; ++kh) {
+      float a[TG][4];
+#pragma unroll
+      for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) a[tg][ks] = abase[(size_t)kh * RS + tg * 16 * st * Ct + 4 * ks];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+        for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) acc[tg][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tg][ks], bw[kh][ks][nt], acc[tg][nt], 0, 0, 0);
+    }
+    // reg rr of lane l = out[ox = ox0 + 16*tg + 4*kq + rr][n = 16*nt + li]  (64-B pieces per store; a transpose through LDS to
+    // float4 stores measured no faster -- the kernel is bound by its short per-strip life, not by the stores)
+#pragma unroll
+    for (int tg = 0; tg < TG; ++tg)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox0 + 16 * tg + 4 * kq + rr;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          const size_t idx = pix * N + nt * 16 + li;
+          p.C[idx] = bg::apply_epilogue(p, acc[tg][nt][rr], idx, nt * 16 + li);
+        }
+      }
+  }
+}
+
+template <int K>
+int launch_rows_gather(const RowGParams& p, int tg, dim3 grid, size_t lds, hipStream_t s) {
+  const int nt = p.N / 16;
+#define BG_RG(TGv, NTv) hipLaunchKernelGGL((conv_rows_gather_kernel<TGv, NTv, K>), grid, dim3(256), lds, s, p)
+  if (tg == 1) { if (nt == 1) BG_RG(1, 1); else if (nt == 2) BG_RG(1, 2); else BG_RG(1, 4); }
+  else if (tg == 2) { if (nt == 1) BG_RG(2, 1); else if (nt == 2) BG_RG(2, 2); else BG_RG(2, 4); }
+  else { if (nt == 1) BG_RG(4, 1); else if (nt == 2) BG_RG(4, 2); else BG_RG(4, 4); }
+#undef BG_RG
+  return 1;
+}
+
 }  // namespace
 
 namespace bg {
+
+// thin contraction side (<= 3 channels in): forward of any stride, or the stride-1 data gradient
+int try_conv_rows_gather(int bwd_data, const float* a, const float* w, float* c, int B, int H, int W, int Cin, int Cout, int k, int s,
+                         const bg_epilogue* epi, void* stream, int* taken) {
+  *taken = 0;
+  static const int off = getenv("BG_NO_ROWS") ? 1 : 0;
+  if (off || (k != 5 && k != 3)) return BG_OK;
+  RowGParams p;
+  memset(&p, 0, sizeof p);
+  int Ho, Wo, pt, pl;
+  same_pads(H, k, s, &Ho, &pt);
+  same_pads(W, k, s, &Wo, &pl);
+  if (bwd_data) {      // dy [B,H,W,Cout] (s == 1) -> dx [B,H,W,Cin]
+    if (s != 1 || Cout * k > 16 || (Cin != 16 && Cin != 32 && Cin != 64)) return BG_OK;
+    p.Hi = H; p.Wi = W; p.Ct = Cout; p.Ho = H; p.Wo = W; p.N = Cin; p.s = 1; p.pt = k - 1 - pt; p.pl = k - 1 - pl; p.flip = 1;
+  } else {
+    if (Cin * k > 16 || (Cout != 16 && Cout != 32 && Cout != 64)) return BG_OK;
+    p.Hi = H; p.Wi = W; p.Ct = Cin; p.Ho = Ho; p.Wo = Wo; p.N = Cout; p.s = s; p.pt = pt; p.pl = pl; p.flip = 0;
+  }
+  if (p.Wo % 16 != 0) return BG_OK;
+  if ((size_t)B * p.Ho * p.Wo * p.N >= (1ull << 31)) return BG_OK;
+  const int tiles = p.Wo / 16;
+  const int tg = tiles % 4 == 0 ? 4 : (tiles % 2 == 0 ? 2 : 1);
+  p.A = a; p.Wt = w; p.C = c; p.B = B;
+  static const int rows_r = getenv("BG_ROWSG_R") ? atoi(getenv("BG_ROWSG_R")) : 0;     // tuning aid
+  p.R = std::min(rows_r ? rows_r : (s == 2 ? 8 : 16), p.Ho);
+  p.strips = (int)cdiv(p.Ho, p.R);
+  const size_t lds = ((size_t)((p.R - 1) * p.s + k) * (p.Wi * p.Ct + 2 * kRgHalo)) * sizeof(float);
+  if (lds > 64 * 1024) return BG_OK;
+  p.epi_mode = BG_EPI_NONE; p.alpha = 0.3f; p.scale = 1.f;
+  if (epi) {
+    BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "conv rows: epilogue mode %d", epi->mode);
+    BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || epi->ref, BG_ERR_NULL, "conv rows: BG_EPI_MUL_GRAD needs ref");
+    BG_REQUIRE(epi->mode != BG_EPI_AFFINE_LRELU || (epi->ref && epi->bias), BG_ERR_NULL, "conv rows: BG_EPI_AFFINE_LRELU needs ref and bias");
+    p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep; p.alpha = epi->alpha; p.scale = epi->scale;
+  }
+  const dim3 grid((unsigned)(B * p.strips));
+  const double flops = 2.0 * B * (double)Ho * Wo * Cin * Cout * k * k;
+  Launch L(stream, bwd_data ? "conv_rows_thin_k_dgrad" : "conv_rows_thin_k_fwd", flops, 0);
+  if (k == 5) launch_rows_gather<5>(p, tg, grid, lds, L.s);
+  else launch_rows_gather<3>(p, tg, grid, lds, L.s);
+  *taken = 1;
+  return L.done("conv_rows_gather_kernel");
+}
+
+
 
 // Tries the row kernel for a thin-N problem; returns BG_OK + *taken = 1 when it ran, *taken = 0 when the shape is not covered.
 //   forward (bwd_data = 0): x [B,H,W,Cin] -> y [B,H,W,Cout], stride 1, weights wT [tap][Cout][Cin]
