@@ -106,10 +106,7 @@ def main():
     dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], device="cuda", dtype=torch.float64)
-    if world > 1:
-        torch.distributed.all_reduce(tmax, op=torch.distributed.ReduceOp.MAX)
-    dt = float(tmax.item())
+    dt = dist.max_over_ranks(dt)
     value = B * world * args.steps / dt
 
     # ---- per-kernel HIP-event timing on the launch stream (separate, un-timed steps)

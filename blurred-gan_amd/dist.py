@@ -25,7 +25,11 @@ def world_size():
 
 
 def local_rank():
-    return int(os.environ.get("LOCAL_RANK", "0"))
+    """Device index of this process.  One process per GPU; when a node exposes fewer devices than ranks (the
+    2-ranks-on-one-card rehearsal of tests/test_dp_gpu.py and of bench.py) ranks share devices round-robin."""
+    lr = int(os.environ.get("LOCAL_RANK", "0"))
+    n = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    return lr % n if n > 0 else lr
 
 
 def init_from_env(backend=None):
@@ -37,7 +41,9 @@ def init_from_env(backend=None):
     if use_cuda:
         torch.cuda.set_device(local_rank())
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    td.init_process_group(backend=backend or ("nccl" if use_cuda else "gloo"))
+    # BGAN_DIST_BACKEND=gloo: rehearsal of the multi-rank path where RCCL cannot run (several ranks on one card)
+    backend = backend or os.environ.get("BGAN_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+    td.init_process_group(backend=backend)
     return world_size()
 
 
@@ -51,6 +57,16 @@ def all_reduce_sum_(flat):
         else:
             td.all_reduce(flat, op=td.ReduceOp.SUM)          # RCCL ring/tree over xGMI on the GPU box
     return flat
+
+
+def max_over_ranks(value: float) -> float:
+    """MAX of a host scalar over the replicas (bench timing)."""
+    if world_size() <= 1:
+        return float(value)
+    dev = "cuda" if (td.get_backend() == "nccl") else "cpu"
+    t = torch.tensor([value], dtype=torch.float64, device=dev)
+    td.all_reduce(t, op=td.ReduceOp.MAX)
+    return float(t.item())
 
 
 def broadcast_(flat, src=0):
