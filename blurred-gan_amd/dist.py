@@ -59,6 +59,81 @@ def all_reduce_sum_(flat):
     return flat
 
 
+class GradReducer:
+    """SUM all-reduce of one network's flat gradient buffer, issued in buckets WHILE the backward that fills the buffer is
+    still running: the engine reports each layer's slice as soon as its last contribution has been enqueued, adjacent slices
+    are merged into buckets of >= ``bucket_bytes`` and each bucket goes out as an asynchronous collective (RCCL runs it on
+    its own stream behind the kernels already enqueued; xGMI is point-to-point, so a few multi-MB messages per network beat
+    one message per layer).  ``finish()`` reduces whatever was not reported and waits; Adam runs after it.
+    With one replica every call is a no-op."""
+
+    def __init__(self, flat, n, bucket_bytes=4 << 20):
+        self.flat, self.n = flat, int(n)
+        self.bucket = max(1, int(bucket_bytes) // 4)
+        self.active = world_size() > 1
+        self.pending = None          # (lo, hi) merged, not yet issued
+        self.covered = []            # issued ranges
+        self.works = []
+        self.n_collectives = 0
+
+    def _issue(self, lo, hi):
+        if hi <= lo:
+            return
+        seg = self.flat[lo:hi]
+        self.n_collectives += 1
+        if seg.is_cuda and td.get_backend() == "gloo":          # CPU-side rehearsal: stage through the host, synchronous
+            host = seg.cpu()
+            td.all_reduce(host, op=td.ReduceOp.SUM)
+            seg.copy_(host)
+        else:
+            self.works.append(td.all_reduce(seg, op=td.ReduceOp.SUM, async_op=True))
+        self.covered.append((lo, hi))
+
+    def ready(self, lo, hi):
+        """Elements [lo, hi) of the buffer are final (their last kernel has been enqueued on the current stream).
+        Anything already handed over (issued or pending) is clipped away: no element is ever reduced twice."""
+        if not self.active:
+            return
+        lo, hi = max(0, int(lo)), min(self.n, int(hi))
+        taken = sorted(self.covered + ([self.pending] if self.pending is not None else []))
+        pieces, pos = [], lo
+        for a, b in taken:
+            if b <= pos or a >= hi:
+                continue
+            if a > pos:
+                pieces.append((pos, a))
+            pos = max(pos, b)
+        if pos < hi:
+            pieces.append((pos, hi))
+        for a, b in pieces:
+            if self.pending is not None and (a == self.pending[1] or b == self.pending[0]):   # adjacent: grow the bucket
+                self.pending = (min(a, self.pending[0]), max(b, self.pending[1]))
+            else:
+                if self.pending is not None:
+                    self._issue(*self.pending)
+                self.pending = (a, b)
+            if self.pending[1] - self.pending[0] >= self.bucket:
+                self._issue(*self.pending)
+                self.pending = None
+
+    def finish(self):
+        if not self.active:
+            return
+        if self.pending is not None:
+            self._issue(*self.pending)
+            self.pending = None
+        pos = 0                                                   # whatever no layer reported (padding, unused variables)
+        for lo, hi in sorted(self.covered):
+            if lo > pos:
+                self._issue(pos, lo)
+            pos = max(pos, hi)
+        if pos < self.n:
+            self._issue(pos, self.n)
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
 def max_over_ranks(value: float) -> float:
     """MAX of a host scalar over the replicas (bench timing)."""
     if world_size() <= 1:

@@ -276,9 +276,11 @@ class Net:
         return self.forward(ctx, x, training=training, seed=np.random.randint(1 << 30)).clone()
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ctx: Context, dout, need_dx=False, need_dw=True, beta=0.0, scale=1.0):
+    def backward(self, ctx: Context, dout, need_dx=False, need_dw=True, beta=0.0, scale=1.0, reducer=None):
         """Reverse pass of the last ``forward`` on ``ctx``.  Weight gradients go to ``store.grad``
-        (= beta*old + scale*new).  Returns d(loss)/d(net input) *before* the blur (or None)."""
+        (= beta*old + scale*new).  Returns d(loss)/d(net input) *before* the blur (or None).
+        ``reducer`` (dist.GradReducer): this pass completes the gradients, so each stage's slice of the flat buffer is
+        handed to the bucketed all-reduce as soon as its kernels are enqueued."""
         st_ = self.store
         if need_dw:
             st_.ensure_opt_state()
@@ -345,6 +347,8 @@ class Net:
                     N = st.out_shape[-1]
                     ws = self.workspace(ops.colsum_workspace_bytes(rows, N))
                     ops.colsum(dz, st_.grad_of(lin, "bias"), rows, N, ws, beta=beta, scale=scale)
+                if reducer is not None:
+                    reducer.ready(*st_.train_range(lin, st.bn))
             # ---- input gradient
             if i == 0 and not need_dx:
                 return None
@@ -378,7 +382,7 @@ class Net:
         return din
 
     # ------------------------------------------------------------------ GP second order
-    def gp_second_order(self, ctx: Context, v0):
+    def gp_second_order(self, ctx: Context, v0, reducer=None):
         """SURVEY.md 8a, GP derivation step 2: one linearised forward of the critic on ``v0`` with the
         LeakyReLU masks of the x-hat pass frozen, plus one wgrad per conv layer against the zeta_i kept by
         the first-order backward (``ctx.dz``); accumulates into ``store.grad`` (beta = 1)."""
@@ -397,12 +401,16 @@ class Net:
                                       self.workspace(nb) if nb else None)
                 vo = ctx.buf(ctx.v, i)
                 epi = self._epi(False, Bc, H, W, Ci, lin.filters, lin.k, lin.stride, EPI_MUL_GRAD, ref=ctx.a[i], alpha=st.alpha)
+                if reducer is not None:     # this layer's gradient (first-order pass + this wgrad) is complete
+                    reducer.ready(*st_.train_range(lin, st.bn))
                 ops.conv2d_fwd(vin, self.store.transposed_kernel(lin), vo, lin.k, lin.stride, epi)
                 v = vo
             elif st.kind == "dense" and last and st.out_shape == (1,) and st.bn is None and st.act is None:
                 K = st.in_shape[0]
                 ws = self.workspace(ops.colsum_workspace_bytes(B, K))
                 ops.colsum(v.view(B, K), st_.grad_of(lin, "kernel").view(K), B, K, ws, beta=1.0, scale=1.0)
+                if reducer is not None:
+                    reducer.ready(*st_.train_range(lin, st.bn))
             else:
                 raise NotImplementedError("gradient penalty second order supports the reference critic shape only: "
                                           "[Conv2D+LeakyReLU(+Dropout)]* -> Flatten -> Dense(1) (demo_celeba.py:96-124)")

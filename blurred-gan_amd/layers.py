@@ -232,6 +232,16 @@ class ParamStore:
                 return buf[off:off + int(np.prod(shape))].view(shape)
         raise KeyError(name)
 
+    def train_range(self, *layers):
+        """[lo, hi) of the flat trainable buffer covered by the variables of ``layers`` (None entries ignored)."""
+        lo, hi = None, None
+        for (l, n, off, shape, trainable) in self.entries:
+            if trainable and any(l is x for x in layers if x is not None):
+                end = off + -(-int(np.prod(shape)) // self.ALIGN) * self.ALIGN
+                lo = off if lo is None else min(lo, off)
+                hi = end if hi is None else max(hi, end)
+        return (0, 0) if lo is None else (lo, hi)
+
     def grad_of(self, layer, name):
         self.ensure_opt_state()
         return self.view_like(self.grad, layer, name)

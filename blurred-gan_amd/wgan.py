@@ -247,16 +247,19 @@ class WGAN:
         vs = self._vec_scale(B)
         ops.wgangp_d_loss(fs, rs, norms, inv_gbs, float(getattr(hp, "gp_coefficient", 0.0)) if self.uses_gradient_penalty else 0.0,
                           float(getattr(hp, "e_drift", 0.0)) if self.uses_gradient_penalty else 0.0, vs, ds2[:B], ds2[B:], met)
-        D.backward(cfr, ds2.view(2 * B, 1), need_dx=False, need_dw=True, beta=0.0, scale=1.0)
+        store = self.discriminator.store
+        store.ensure_opt_state()
+        red = dist.GradReducer(store.grad, store.n_train)       # buckets go out while the backward is still running
+        D.backward(cfr, ds2.view(2 * B, 1), need_dx=False, need_dw=True, beta=0.0, scale=1.0,
+                   reducer=None if self.uses_gradient_penalty else red)
         if self.uses_gradient_penalty:
             # d/dW of vec_scale * gp_coefficient * mean_global((n-1)^2): seed carries the whole factor
             coef = vs * float(hp.gp_coefficient) * 2.0 / float(B * dist.world_size())
             gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)))
             chat = D.context(B, "hat")
             v0 = D.apply_blur(gbar, self._buf("v0", tuple(g.shape))) if D.blur is not None else gbar
-            D.gp_second_order(chat, v0)
-        store = self.discriminator.store
-        dist.all_reduce_sum_(store.grad[:store.n_train])
+            D.gp_second_order(chat, v0, reducer=red)
+        red.finish()
         self.discriminator.optimizer.apply(store)
         self._d_metrics_dev = met
         if self.sync_metrics:
@@ -314,9 +317,11 @@ class WGAN:
         met = self._buf("g_metrics", (4,))
         ops.wgan_g_loss(s, 1.0 / float(self.hparams.global_batch_size), ds, met)
         dfakes = D.backward(chat, ds.view(B, 1), need_dx=True, need_dw=False)
-        G.backward(cg, dfakes, need_dx=False, need_dw=True, beta=0.0, scale=1.0)
         store = self.generator.store
-        dist.all_reduce_sum_(store.grad[:store.n_train])
+        store.ensure_opt_state()
+        red = dist.GradReducer(store.grad, store.n_train)
+        G.backward(cg, dfakes, need_dx=False, need_dw=True, beta=0.0, scale=1.0, reducer=red)
+        red.finish()
         self.generator.optimizer.apply(store)
         self._g_metrics_dev = met
         if self.sync_metrics:

@@ -43,6 +43,19 @@ def _worker(rank, world, port, out_dir):
     parts = [torch.zeros_like(local) for _ in range(world)]
     torch.distributed.all_gather(parts, local)
     assert torch.allclose(gflat, sum(parts), rtol=0, atol=1e-12)        # SUM semantics
+    # bucketed reducer: slices reported out of order, with gaps and an overlap, buckets smaller than some slices
+    g = torch.Generator().manual_seed(100 + rank)
+    buf = torch.rand(1000, generator=g, dtype=torch.float64)
+    mine = buf.clone()
+    red = dist.GradReducer(buf, 990, bucket_bytes=4 * 64)
+    for lo, hi in [(900, 990), (800, 900), (300, 420), (400, 500), (0, 16)]:
+        red.ready(lo, hi)
+    red.finish()
+    parts = [torch.zeros_like(mine) for _ in range(world)]
+    torch.distributed.all_gather(parts, mine)
+    assert torch.allclose(buf[:990], sum(parts)[:990], rtol=0, atol=1e-12), "every element reduced exactly once"
+    assert torch.equal(buf[990:], mine[990:]), "elements past n untouched"
+    assert red.n_collectives >= 4
     dist.barrier()
     if rank == 0:
         np.save(os.path.join(out_dir, "d_allreduced.npy"), flat.numpy())
@@ -70,3 +83,7 @@ def test_single_process_dist_helpers_are_noops():
     t = torch.arange(4.0)
     assert torch.equal(dist.all_reduce_sum_(t.clone()), t)
     assert torch.equal(dist.shard(torch.arange(8), r=1, n=4), torch.tensor([2, 3]))
+    red = dist.GradReducer(t.clone(), 4)
+    red.ready(0, 2)
+    red.finish()
+    assert red.n_collectives == 0 and dist.max_over_ranks(1.5) == 1.5
