@@ -34,6 +34,8 @@ struct GatherParams {
   int mtiles, xcd_swizzle;   // MFMA kernel: M tiles per phase, XCD-aware tile order on/off
   int pos_major;       // M index order: 0 = (b, a, bx) image-major; 1 = (a, bx, b) position-major (small feature maps: the rows of
                        // a tile then share their spatial position, so zero-padding taps are skipped for the whole tile)
+  int pmerge;          // MFMA kernel: sub-pixel phases handled by ONE workgroup (1, 2 or 4): the K loop runs through their tap lists
+                       // back to back and each phase's tile is stored when its taps are done (short-K transposed convs)
   int ksplit;          // split-K factor of the MFMA kernel (1 = none); partial sums go to slab[split][B*Hd*Wd*N]
   float* slab;
   // epilogue

@@ -47,9 +47,14 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
   __shared__ int rowdst[BM];
   __shared__ int taplist[bg::kMaxTaps];
+  __shared__ int phase_steps[bg::kMaxPhases], phase_dd[bg::kMaxPhases];
 
-  const int phase = blockIdx.z % p.nphase, split = blockIdx.z / p.nphase;
-  const GatherPhase& g = p.ph[phase];
+  // A workgroup owns one output tile of `pm` sub-pixel phases (same anchors, different tap sets and destination offsets).
+  // pm = 2 pairs the 9-tap with the 4-tap phase and the two 6-tap phases.
+  const int pm = p.pmerge, ngroups = p.nphase / pm;
+  const int pgrp = blockIdx.z % ngroups, split = blockIdx.z / ngroups;
+  auto phase_of = [&](int q) { return pm == 2 ? (q == 0 ? pgrp : p.nphase - 1 - pgrp) : pgrp * pm + q; };
+  const GatherPhase& g = p.ph[phase_of(0)];
   const int Mph = p.B * g.Ha * g.Wa;
   // logical tile list is n-major (all M tiles of one weight panel, then the next panel): with the XCD remap each
   // XCD's L2 holds only its share of the weight panels while the activations stream through
@@ -95,20 +100,29 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   // Taps whose source pixel is zero padding for EVERY row of the tile are dropped from the K loop (no loads, no MFMAs).
   // Only position-major tiles can lose taps (all their rows sit at ONE output position; a pixel-major tile spans whole image
   // rows, where every tap is in range for some pixel), and there the mask follows from any one row: no exchange needed.
-  unsigned tmask = g.ntaps >= 32 ? 0xffffffffu : ((1u << g.ntaps) - 1u);
-  if (p.pos_major) {
-    unsigned bits = 0u;
-    for (int t = 0; t < g.ntaps; ++t) {
-      const int dy = bg::tap_dy(g.tap[t]), dx = bg::tap_dx(g.tap[t]);
-      bits |= ((unsigned)(a_y[0] + dy) < (unsigned)p.Hs && (unsigned)(a_x[0] + dx) < (unsigned)p.Ws) ? (1u << t) : 0u;
+  const int kchunks = p.Ck / BK;
+  int tbase = 0;
+  for (int q = 0; q < pm; ++q) {
+    const GatherPhase& gq = p.ph[phase_of(q)];
+    unsigned tmask = gq.ntaps >= 32 ? 0xffffffffu : ((1u << gq.ntaps) - 1u);
+    if (p.pos_major) {
+      unsigned bits = 0u;
+      for (int t = 0; t < gq.ntaps; ++t) {
+        const int dy = bg::tap_dy(gq.tap[t]), dx = bg::tap_dx(gq.tap[t]);
+        bits |= ((unsigned)(a_y[0] + dy) < (unsigned)p.Hs && (unsigned)(a_x[0] + dx) < (unsigned)p.Ws) ? (1u << t) : 0u;
+      }
+      tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)bits);
     }
-    tmask = (unsigned)__builtin_amdgcn_readfirstlane((int)bits);
+    if (tid < gq.ntaps && ((tmask >> tid) & 1u)) taplist[tbase + __popc(tmask & ((1u << tid) - 1u))] = gq.tap[tid];
+    if (tid == 0) {
+      phase_steps[q] = __popc(tmask) * kchunks;
+      phase_dd[q] = (gq.py - g.py) * p.Wd + (gq.px - g.px);
+    }
+    tbase += __popc(tmask);
   }
-  const int ntaps_c = __popc(tmask);
-  if (tid < g.ntaps && ((tmask >> tid) & 1u)) taplist[__popc(tmask & ((1u << tid) - 1u))] = g.tap[tid];
+  const int ntaps_c = tbase;
   __syncthreads();
 
-  const int kchunks = p.Ck / BK;
   const int nsteps_all = ntaps_c * kchunks;
   const int s_begin = (int)((long)nsteps_all * split / p.ksplit);          // this workgroup's slice of the K steps
   const int nsteps = (int)((long)nsteps_all * (split + 1) / p.ksplit) - s_begin;
@@ -218,30 +232,47 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  // ---- epilogue of one phase: acc reg r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]; the accumulators
+  // restart from zero for the next phase of the group.  It runs between two K steps: the loads of the next phase's tiles are
+  // already in flight and its first fragments already in registers, so only the stores themselves sit between the MFMAs.
+  const int col = lane & 31, rhalf = (lane >> 5) * 4;
+  auto epilogue = [&](int q) {
+    const int dd = phase_dd[q];
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NI; ++j) {
+        const int n = n0 + wn * WTN + j * 32 + col;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
+          const int dst = rowdst[row];
+          if (dst >= 0 && n < p.N) {
+            const size_t idx = (size_t)(dst + dd) * p.N + n;
+            if (p.ksplit > 1) p.slab[(size_t)split * ((size_t)p.B * p.Hd * p.Wd * p.N) + idx] = acc[i][j][r];
+            else p.C[idx] = bg::apply_epilogue_pre(p, acc[i][j][r], idx, e_bias[j], e_mul[j]);
+          }
+          acc[i][j][r] = 0.f;
+        }
+      }
+  };
+  // steps left in the phase being accumulated (pm == 1: the workgroup's whole K slice); phases without a live tap store zeros
+  int c_q = 0, c_left = pm == 1 ? nsteps : phase_steps[0];
+  auto phase_done = [&]() {
+    do {
+      epilogue(c_q);
+      ++c_q;
+      c_left = c_q < pm ? phase_steps[c_q] : -1;
+    } while (c_left == 0);
+  };
+  if (c_left == 0) phase_done();
   const int nsteps2 = (nsteps + 1) & ~1;                       // steps come in (even, odd) pairs; a padded step adds zeros
   for (int step = 0; step < nsteps2; step += 2) {
     step_body(0, [&]() { lstore(1, regA1, regB1); gload(regA1, regB1); });
+    if (--c_left == 0) phase_done();
     step_body(1, [&]() { lstore(0, regA0, regB0); gload(regA0, regB0); });
+    if (--c_left == 0) phase_done();
   }
-
-  // ---- epilogue: acc reg r of lane l holds C[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
-  const int col = lane & 31, rhalf = (lane >> 5) * 4;
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NI; ++j) {
-      const int n = n0 + wn * WTN + j * 32 + col;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + rhalf;
-        const int dst = rowdst[row];
-        if (dst >= 0 && n < p.N) {
-          const size_t idx = (size_t)dst * p.N + n;
-          if (p.ksplit > 1) p.slab[(size_t)split * ((size_t)p.B * p.Hd * p.Wd * p.N) + idx] = acc[i][j][r];
-          else p.C[idx] = bg::apply_epilogue_pre(p, acc[i][j][r], idx, e_bias[j], e_mul[j]);
-        }
-      }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -664,7 +695,24 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
   p.mtiles = (int)bg::cdiv(Mmax, BM);
   static const int no_swz = getenv("BG_NO_XCD_SWIZZLE") ? 1 : 0;
   p.xcd_swizzle = !no_swz;
-  dim3 grid(p.mtiles * bg::cdiv(p.N, BN), 1, p.nphase * ks);
+  // Phases per workgroup: short-K transposed convs (2-18 K steps per phase) spend a quarter of their time in prologue and
+  // epilogue; merging the 4 (or 2) phases of a tile into one workgroup pays the prologue once and hides the epilogues, as long
+  // as the grid still fills the chip 4 workgroups per CU.
+  p.pmerge = 1;
+  if (p.nphase == 4 && ks == 1) {
+    bool same = true;
+    for (int i = 1; i < 4; ++i) same = same && p.ph[i].Ha == p.ph[0].Ha && p.ph[i].Wa == p.ph[0].Wa;
+    int maxsteps = 0;
+    for (int i = 0; i < 4; ++i) maxsteps = std::max(maxsteps, p.ph[i].ntaps * (p.Ck / BK));
+    const long wgs4 = (long)p.mtiles * bg::cdiv(p.N, BN);
+    static const int force_pm = getenv("BG_PMERGE") ? atoi(getenv("BG_PMERGE")) : 0;   // tuning aid
+    if (same) {
+      if (force_pm) p.pmerge = force_pm;
+      else if (maxsteps <= 40 && wgs4 >= 1024) p.pmerge = 4;
+      else if (maxsteps <= 40 && 2 * wgs4 >= 1024) p.pmerge = 2;
+    }
+  }
+  dim3 grid(p.mtiles * bg::cdiv(p.N, BN), 1, (p.nphase / p.pmerge) * ks);
   {
     bg::Launch L(stream, name, gather_flops(p), 0);
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
