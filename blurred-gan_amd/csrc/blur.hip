@@ -9,6 +9,7 @@
 //                      (traffic 2x algorithmic); any size / tap count.
 #include "common.h"
 #include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -82,6 +83,96 @@ __global__ __launch_bounds__(kFusedThreads) void blur_fused_kernel(const float* 
 #pragma unroll
     for (int r = 0; r < kR; ++r)
       if (w0 + r < W) yi[(h * W + w0 + r) * C + c] = acc[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Matrix-core form for images up to 64 x 64 (every blur of the 64-pixel models): a 1-D blur with SAME zero padding is a
+// banded Toeplitz matrix,  Y_c = T_H X_c  then  Z_c = Y_c T_W^T  per channel plane, with T[a][b] = taps[b - a + half].
+// At 64 pixels the band (31 taps at sigma 5, 143 at sigma 23.5) covers half to all of the matrix, so the dense product on
+// v_mfma_f32_32x32x2_f32 (exact fp32 products) costs 2 * 2*64^3 flop per plane REGARDLESS of the tap count and beats the
+// sliding-window VALU kernel from ~13 taps up; the cost no longer grows with sigma (the reference starts training at
+// sigma 23.5).  One workgroup per image: planes de-interleaved into LDS (row stride odd -> the transposed fragment reads of
+// the W pass are conflict-free), Toeplitz fragments read from a zero-padded copy of the taps, result re-interleaved on the
+// way out.  HBM traffic == algorithmic (8*H*W*C bytes per image).
+// ------------------------------------------------------------------------------------------------
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+constexpr int kTzPad = 64;
+
+constexpr int kMfmaBlurThreads = 1024;   // 16 waves: the load / de-interleave and re-interleave / store phases are latency-bound
+
+struct FastDiv { unsigned mul, sh; };    // floor(v / d) for v < 2^20: (v * mul) >> sh
+__device__ inline int fdiv(int v, FastDiv f) { return (int)(((unsigned long long)(unsigned)v * f.mul) >> f.sh); }
+
+__global__ __launch_bounds__(kMfmaBlurThreads) void blur_mfma_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                                                                     int Hp, int Wp, const float* __restrict__ taps, int T, FastDiv dC, FastDiv dW) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NTH = kMfmaBlurThreads;
+  const int SP = Wp + 1;                                     // plane row stride (odd)
+  const int plane = Hp * SP;
+  float* X = lds;                                            // [C][Hp][SP]  input planes, later the output planes
+  float* Y = lds + C * plane;                                // [C][Hp][SP]  after the H pass
+  float* tz = lds + 2 * C * plane;                           // [kTzPad zeros][T taps][kTzPad zeros]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = T >> 1, n = H * W * C;
+  const float* xi = x + (size_t)blockIdx.x * n;
+  float* yi = y + (size_t)blockIdx.x * n;
+  auto plane_off = [&](int e) {                              // NHWC element -> offset in the de-interleaved planes
+    const int pix = fdiv(e, dC), c = e - pix * C;
+    const int yy = fdiv(pix, dW), xx = pix - yy * W;
+    return c * plane + yy * SP + xx;
+  };
+  for (int j = tid; j < T + 2 * kTzPad; j += NTH) tz[j] = (j >= kTzPad && j < kTzPad + T) ? taps[j - kTzPad] : 0.f;
+  if (Hp != H || Wp != W) {                                  // padding rows / columns must read as zero
+    for (int e = tid; e < C * plane; e += NTH) X[e] = 0.f;
+    __syncthreads();
+  }
+  if ((n & 3) == 0) {
+    for (int e = tid * 4; e < n; e += NTH * 4) {
+      const float4 v = *reinterpret_cast<const float4*>(xi + e);
+      X[plane_off(e)] = v.x; X[plane_off(e + 1)] = v.y; X[plane_off(e + 2)] = v.z; X[plane_off(e + 3)] = v.w;
+    }
+  } else {
+    for (int e = tid; e < n; e += NTH) X[plane_off(e)] = xi[e];
+  }
+  __syncthreads();
+  const int mts = Hp / 32, nts = Wp / 32, ntiles = C * mts * nts;
+  const int li = lane & 31, kk = lane >> 5;
+  // ---- H pass: Y_c[y][x] = sum_y' taps[y' - y + half] * X_c[y'][x];  A = Toeplitz, B = X rows
+  for (int tile = wave; tile < ntiles; tile += NTH / 64) {
+    const int c = tile / (mts * nts), r = tile - c * mts * nts, mt = r / nts, nt = r - mt * nts;
+    floatx16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const float* ta = tz + kTzPad + half - (32 * mt + li) + kk;     // + k
+    const float* xb = X + c * plane + kk * SP + 32 * nt + li;       // + k * SP
+#pragma unroll 8
+    for (int kp = 0; kp < Hp / 2; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[2 * kp], xb[2 * kp * SP], acc, 0, 0, 0);
+    float* yo = Y + c * plane + (32 * mt + 4 * kk) * SP + 32 * nt + li;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) yo[((q & 3) + 8 * (q >> 2)) * SP] = acc[q];
+  }
+  __syncthreads();
+  // ---- W pass: Z_c[y][x] = sum_x' Y_c[y][x'] * taps[x' - x + half];  A = Y rows (transposed read), B = Toeplitz
+  for (int tile = wave; tile < ntiles; tile += NTH / 64) {
+    const int c = tile / (mts * nts), r = tile - c * mts * nts, mt = r / nts, nt = r - mt * nts;
+    floatx16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const float* ya = Y + c * plane + (32 * mt + li) * SP + kk;     // + k
+    const float* tb = tz + kTzPad + half - (32 * nt + li) + kk;     // + k
+#pragma unroll 8
+    for (int kp = 0; kp < Wp / 2; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[2 * kp], tb[2 * kp], acc, 0, 0, 0);
+    float* zo = X + c * plane + (32 * mt + 4 * kk) * SP + 32 * nt + li;   // X is dead: every wave passed the barrier above
+#pragma unroll
+    for (int q = 0; q < 16; ++q) zo[((q & 3) + 8 * (q >> 2)) * SP] = acc[q];
+  }
+  __syncthreads();
+  if ((n & 3) == 0) {
+    for (int e = tid * 4; e < n; e += NTH * 4)
+      *reinterpret_cast<float4*>(yi + e) = make_float4(X[plane_off(e)], X[plane_off(e + 1)], X[plane_off(e + 2)], X[plane_off(e + 3)]);
+  } else {
+    for (int e = tid; e < n; e += NTH) yi[e] = X[plane_off(e)];
   }
 }
 
@@ -258,6 +349,31 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   const size_t total = (size_t)B * H * W * C;
   const double flops = 4.0 * n_taps * (double)total, bytes = 8.0 * (double)total;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  {
+    static const int mfma_min_taps = getenv("BG_BLUR_MFMA_MIN_TAPS") ? atoi(getenv("BG_BLUR_MFMA_MIN_TAPS")) : 13;
+    const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
+    const size_t lds_m = ((size_t)2 * C * Hp * (Wp + 1) + n_taps + 2 * kTzPad) * sizeof(float);
+    if (H <= 64 && W <= 64 && C <= 16 && n_taps >= mfma_min_taps && lds_m <= kFusedLdsCap) {
+      static bool attr_m = false;
+      if (!attr_m) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsCap);
+        if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "bg_blur_nhwc_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+        attr_m = true;
+      }
+      auto magic = [](unsigned d) {           // exact for dividends < 2^20 (n = H*W*C <= 64*64*16)
+        FastDiv f;
+        unsigned sft = 0;
+        while ((1u << sft) < d) ++sft;
+        f.sh = 20 + sft;
+        f.mul = (unsigned)(((1ull << f.sh) + d - 1) / d);
+        return f;
+      };
+      bg::Launch L(stream, "blur_mfma", flops, bytes);
+      hipLaunchKernelGGL(blur_mfma_kernel, dim3(B), dim3(kMfmaBlurThreads), lds_m, s, x, y, H, W, C, Hp, Wp, taps_d, n_taps, magic((unsigned)C),
+                         magic((unsigned)W));
+      return L.done("blur_mfma_kernel");
+    }
+  }
   const size_t lds = fused_lds_bytes(H, W, C);
   if (lds <= kFusedLdsCap && n_taps <= 500) {
     static bool attr_set = false;
