@@ -9,6 +9,7 @@
 //   wgrad_direct_kernel thin / odd channel counts: one thread per (tap, ci, co) output and pixel slice.
 #include "conv_common.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -1157,10 +1158,35 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
   }
   }
   const long base = (long)pl.tiles_m * pl.tiles_n * (pl.taps_in_grid == 1 ? kk : (pl.taps_in_grid == 2 ? k : 1));
-  long want = std::max(1L, (768 + base - 1) / base);            // aim for ~3 workgroups per CU
-  long steps = (M + pl.bkp - 1) / pl.bkp;
-  want = std::min(want, std::max(1L, steps / 4));               // at least 4 K-steps per workgroup
-  if ((size_t)kk * Ci * Co * sizeof(float) > (8u << 20)) want = std::min(want, 2L);   // big slabs: the reduce pass costs more than idle CUs
+  const long steps = (M + pl.bkp - 1) / pl.bkp;
+  long want;
+  static const int old_plan = getenv("BG_WGRAD_OLD_PLAN") ? 1 : 0;
+  // position-major small maps skip their all-padding chunks: workgroup lengths differ 4x between centre and corner taps, and
+  // more, shorter workgroups balance better than the round model predicts (measured: G1 0.33 ms at 800 workgroups, 0.40 at 400)
+  const bool skipping = Ho * Wo <= 16 && B >= 128 && (B & (B - 1)) == 0;
+  if (old_plan || pl.taps_in_grid != 1 || skipping) {
+    want = std::max(1L, (768 + base - 1) / base);                 // aim for ~3 workgroups per CU
+    want = std::min(want, std::max(1L, steps / 4));               // at least 4 K-steps per workgroup
+    if ((size_t)kk * Ci * Co * sizeof(float) > (8u << 20)) want = std::min(want, 2L);   // big slabs: the reduce pass costs more than idle CUs
+  } else {
+    // Pixel split from a cost model instead of a fixed workgroup target: the grid runs in ROUNDS of (workgroups resident per
+    // CU) x 256, and a grid that spills a little into the next round pays for a whole one (800 workgroups on 512 slots ran
+    // at 78 %).  cost(ks) = rounds x (K steps per workgroup + prologue/epilogue) x step time  +  slab reduce.
+    const int lds = 2 * pl.bkp * (bm + bn) * 4;
+    const int per_cu = std::max(1, std::min(160 * 1024 / lds, 5));
+    const double slots = 256.0 * per_cu;
+    const double t_step = 2.0 * bm * bn * pl.bkp * per_cu / 614e9 * 1e6;          // us per K step with the CU fully resident
+    const double ovh = 5.0 / t_step;                                                // prologue + tile store, in steps
+    const double nout_bytes = (double)kk * Ci * Co * 4.0;
+    double best = 1e30;
+    want = 1;
+    for (long ks = 1; ks <= std::min<long>(64, std::max(1L, steps / 4)); ++ks) {
+      const double rounds = std::ceil(base * ks / slots);
+      const double per_wg = std::ceil((double)steps / ks);
+      const double cost = rounds * (per_wg + ovh) * t_step + (ks > 1 ? 5.0 + (ks + 1) * nout_bytes / 3.5e6 + ks * nout_bytes / 5e6 : 0.0);
+      if (cost < best * 0.999) { best = cost; want = ks; }
+    }
+  }
   long chunk = ((M + want - 1) / want + pl.bkp - 1) / pl.bkp * pl.bkp;
   pl.chunk = (int)chunk;
   pl.ksplit = (int)((M + chunk - 1) / chunk);
