@@ -671,8 +671,10 @@ int plan_splitk(const GatherParams& p, int bm, int bn, int bk) {
   const long wgs = (long)bg::cdiv(max_phase_m(p), bm) * bg::cdiv(p.N, bn) * p.nphase;
   int min_steps = 1 << 30;
   for (int i = 0; i < p.nphase; ++i) min_steps = std::min(min_steps, p.ph[i].ntaps * (p.Ck / bk));
-  if (wgs >= 512 || min_steps < 32) return 1;
-  int ks = (int)std::min<long>(8, (768 + wgs - 1) / wgs);
+  static const int min_wgs = getenv("BG_SPLITK_MIN_WGS") ? atoi(getenv("BG_SPLITK_MIN_WGS")) : 512;
+  static const int tgt_wgs = getenv("BG_SPLITK_TARGET") ? atoi(getenv("BG_SPLITK_TARGET")) : 768;
+  if (wgs >= min_wgs || min_steps < 32) return 1;
+  int ks = (int)std::min<long>(8, (tgt_wgs + wgs - 1) / wgs);
   ks = std::min(ks, min_steps / 16);
   return std::max(ks, 1);
 }

@@ -1164,7 +1164,7 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
   // position-major small maps skip their all-padding chunks: workgroup lengths differ 4x between centre and corner taps, and
   // more, shorter workgroups balance better than the round model predicts (measured: G1 0.33 ms at 800 workgroups, 0.40 at 400)
   const bool skipping = Ho * Wo <= 16 && B >= 128 && (B & (B - 1)) == 0;
-  if (old_plan || pl.taps_in_grid != 1 || skipping) {
+  if (old_plan || pl.taps_in_grid != 1 || skipping) {     // tap-grouped kernel: measured slower with the model's single full round (0.35 vs 0.28 ms)
     want = std::max(1L, (768 + base - 1) / base);                 // aim for ~3 workgroups per CU
     want = std::min(want, std::max(1L, steps / 4));               // at least 4 K-steps per workgroup
     if ((size_t)kk * Ci * Co * sizeof(float) > (8u << 20)) want = std::min(want, 2L);   // big slabs: the reduce pass costs more than idle CUs
@@ -1172,10 +1172,11 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
     // Pixel split from a cost model instead of a fixed workgroup target: the grid runs in ROUNDS of (workgroups resident per
     // CU) x 256, and a grid that spills a little into the next round pays for a whole one (800 workgroups on 512 slots ran
     // at 78 %).  cost(ks) = rounds x (K steps per workgroup + prologue/epilogue) x step time  +  slab reduce.
-    const int lds = 2 * pl.bkp * (bm + bn) * 4;
+    const int bm_eff = pl.taps_in_grid == 2 ? k * bm : bm;           // the tap-grouped kernel holds k tap tiles of x per step
+    const int lds = 2 * pl.bkp * (bm_eff + bn) * 4;
     const int per_cu = std::max(1, std::min(160 * 1024 / lds, 5));
     const double slots = 256.0 * per_cu;
-    const double t_step = 2.0 * bm * bn * pl.bkp * per_cu / 614e9 * 1e6;          // us per K step with the CU fully resident
+    const double t_step = 2.0 * bm_eff * bn * pl.bkp * per_cu / 614e9 * 1e6;      // us per K step with the CU fully resident
     const double ovh = 5.0 / t_step;                                                // prologue + tile store, in steps
     const double nout_bytes = (double)kk * Ci * Co * 4.0;
     double best = 1e30;
