@@ -673,7 +673,8 @@ int plan_splitk(const GatherParams& p, int bm, int bn, int bk) {
   for (int i = 0; i < p.nphase; ++i) min_steps = std::min(min_steps, p.ph[i].ntaps * (p.Ck / bk));
   static const int min_wgs = getenv("BG_SPLITK_MIN_WGS") ? atoi(getenv("BG_SPLITK_MIN_WGS")) : 512;
   static const int tgt_wgs = getenv("BG_SPLITK_TARGET") ? atoi(getenv("BG_SPLITK_TARGET")) : 768;
-  if (wgs >= min_wgs || min_steps < 32) return 1;
+  if (wgs >= 2 * min_wgs || min_steps < 32) return 1;
+  if (wgs >= min_wgs) return min_steps >= 200 ? 2 : 1;      // half a round of workgroups: worth a reduce pass only on very long K loops (G1: -5 %)
   int ks = (int)std::min<long>(8, (tgt_wgs + wgs - 1) / wgs);
   ks = std::min(ks, min_steps / 16);
   return std::max(ks, 1);
