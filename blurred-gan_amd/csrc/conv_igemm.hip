@@ -14,6 +14,7 @@
 //                       of 16); used by small test geometries only.
 #include "conv_common.h"
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
 
 namespace {
@@ -711,8 +712,22 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
     static const int force_pm = getenv("BG_PMERGE") ? atoi(getenv("BG_PMERGE")) : 0;   // tuning aid
     if (same) {
       if (force_pm) p.pmerge = force_pm;
-      else if (maxsteps <= 40 && wgs4 >= 1024) p.pmerge = 4;
-      else if (maxsteps <= 40 && 2 * wgs4 >= 1024) p.pmerge = 2;
+      else {
+        // rounds of resident workgroups x (K steps of the longest workgroup + prologue/epilogue), as in plan_wgrad
+        const int lds = 2 * (BM + BN) * (BK + 4) * 4;
+        const long slots = 256L * std::max(1, std::min(160 * 1024 / lds, 4));
+        const int kc = p.Ck / BK;
+        int tot = 0, t03 = p.ph[0].ntaps + p.ph[3].ntaps, t12 = p.ph[1].ntaps + p.ph[2].ntaps;
+        for (int i = 0; i < 4; ++i) tot += p.ph[i].ntaps;
+        const double longest[3] = {(double)maxsteps, (double)std::max(t03, t12) * kc, (double)tot * kc};   // pm = 1, 2, 4
+        double best = 1e30;
+        for (int i = 0; i < 3; ++i) {
+          const int pmv = 1 << i;
+          const double rounds = std::ceil((double)wgs4 * (4 / pmv) / slots);
+          const double cost = rounds * (longest[i] + 2.5);
+          if (cost < best * 0.97) { best = cost; p.pmerge = pmv; }      // prefer fewer merges on a tie
+        }
+      }
     }
   }
   dim3 grid(p.mtiles * bg::cdiv(p.N, BN), 1, (p.nphase / p.pmerge) * ks);
