@@ -41,6 +41,7 @@ SIGNATURES = {
     "bg_conv2d_bwd_filter_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
     "bg_conv2d_bwd_filter": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, _f, _f, _p, _z, _p]),
     "bg_transpose_last2": (_i, [_p, _p, _i, _i, _i, _p]),
+    "bg_transpose_last2_batched": (_i, [_p, _p, _p, _i, _i, _p]),
     "bg_gemm_f32": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _p, _f, _f, _p]),
     "bg_colsum_workspace_bytes": (_z, [_i, _i]),
     "bg_colsum_f32": (_i, [_p, _p, _i, _i, _i, _f, _f, _p, _z, _p]),

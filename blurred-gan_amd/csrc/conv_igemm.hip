@@ -652,6 +652,52 @@ __global__ __launch_bounds__(256) void transpose_last2_kernel(const float* __res
     if (c0 + i < C && r0 + tx < R) d[(size_t)(c0 + i) * R + r0 + tx] = tile[tx][i];
 }
 
+// All kernels of one network in ONE launch: desc[e] = {src_off, dst_off, T, R, C, first_tile} (float offsets into the two base
+// pointers; 64 x 64 tiles numbered [t][r-tile][c-tile] from first_tile).  float4 on both sides when R and C are multiples of 4.
+struct TransposeDesc { int src_off, dst_off, T, R, C, first_tile; };
+
+__global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __restrict__ src_base, float* __restrict__ dst_base,
+                                                                const TransposeDesc* __restrict__ desc, int n) {
+  __shared__ float tile[64][65];
+  int e = 0;
+  while (e + 1 < n && desc[e + 1].first_tile <= (int)blockIdx.x) ++e;      // wave-uniform scan of a short table
+  const TransposeDesc d = desc[e];
+  const int tr = (d.R + 63) / 64, tc = (d.C + 63) / 64;
+  int local = blockIdx.x - d.first_tile;
+  const int t = local / (tr * tc);
+  local -= t * tr * tc;
+  const int r0 = (local / tc) * 64, c0 = (local % tc) * 64;
+  const float* s = src_base + d.src_off + (size_t)t * d.R * d.C;
+  float* o = dst_base + d.dst_off + (size_t)t * d.R * d.C;
+  const int tid = threadIdx.x;
+  if (((d.R | d.C) & 3) == 0) {
+    const int q = tid & 15, rr = tid >> 4;                    // 16 float4 across 64 columns, 16 rows per pass
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int r = r0 + rr + 16 * i, c = c0 + 4 * q;
+      if (r < d.R && c < d.C) {
+        const float4 v = *reinterpret_cast<const float4*>(s + (size_t)r * d.C + c);
+        tile[rr + 16 * i][4 * q] = v.x; tile[rr + 16 * i][4 * q + 1] = v.y; tile[rr + 16 * i][4 * q + 2] = v.z; tile[rr + 16 * i][4 * q + 3] = v.w;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = c0 + rr + 16 * i, r = r0 + 4 * q;
+      if (c < d.C && r < d.R)
+        *reinterpret_cast<float4*>(o + (size_t)c * d.R + r) =
+            make_float4(tile[4 * q][rr + 16 * i], tile[4 * q + 1][rr + 16 * i], tile[4 * q + 2][rr + 16 * i], tile[4 * q + 3][rr + 16 * i]);
+    }
+  } else {
+    const int tx = tid & 63, ty = tid >> 6;
+    for (int i = ty; i < 64; i += 4)
+      if (r0 + i < d.R && c0 + tx < d.C) tile[i][tx] = s[(size_t)(r0 + i) * d.C + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4)
+      if (c0 + i < d.C && r0 + tx < d.R) o[(size_t)(c0 + i) * d.R + r0 + tx] = tile[tx][i];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
@@ -953,6 +999,16 @@ int bg_transpose_last2(const float* src, float* dst, int T, int R, int C, void* 
   bg::Launch L(stream, "transpose_last2", 0, 8.0 * T * R * C);
   hipLaunchKernelGGL(transpose_last2_kernel, dim3(bg::cdiv(C, 32), bg::cdiv(R, 32), T), dim3(256), 0, L.s, src, dst, R, C);
   return L.done("transpose_last2_kernel");
+}
+
+int bg_transpose_last2_batched(const float* src_base, float* dst_base, const int* desc_d, int n, int total_tiles, void* stream) {
+  BG_REQUIRE(src_base && dst_base && desc_d, BG_ERR_NULL, "bg_transpose_last2_batched: null pointer");
+  BG_REQUIRE(n > 0 && total_tiles > 0, BG_ERR_BAD_SHAPE, "bg_transpose_last2_batched: n=%d tiles=%d", n, total_tiles);
+  BG_REQUIRE(bg::aligned16(src_base) && bg::aligned16(dst_base), BG_ERR_BAD_ALIGNMENT, "bg_transpose_last2_batched: bases must be 16-byte aligned");
+  bg::Launch L(stream, "transpose_last2", 0, 0);
+  hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, L.s, src_base, dst_base,
+                     reinterpret_cast<const TransposeDesc*>(desc_d), n);
+  return L.done("transpose_batched_kernel");
 }
 
 }  // extern "C"

@@ -250,17 +250,36 @@ class ParamStore:
         """[k*k][C][R] copy of a conv kernel stored [k*k][R][C]; refreshed after every optimiser step."""
         t = self._tr.get(id(layer))
         if t is None:
-            t = torch.empty(layer.vars["kernel"].numel(), dtype=torch.float32, device=self.device)
-            self._tr[id(layer)] = t
-            self.tr_dirty = True
+            raise KeyError("transposed kernels are laid out by refresh_transposed(); call Net.prepare_weights() first")
         return t
 
-    def refresh_transposed(self, layers):
-        from . import ops
+    def _plan_transposed(self, layers):
+        """One flat buffer for every transposed copy + the device descriptor table of the batched transpose."""
+        offs, desc, off, tile = {}, [], 0, 0
         for layer in layers:
             w = layer.vars["kernel"]
             k2, R, Cc = w.shape[0] * w.shape[1], w.shape[2], w.shape[3]
-            ops.transpose_last2(w, self.transposed_kernel(layer), k2, R, Cc)
+            src_off = (w.data_ptr() - self.theta.data_ptr()) // 4
+            assert 0 <= src_off < self.theta.numel() and src_off % 4 == 0
+            desc.append([src_off, off, k2, R, Cc, tile])
+            offs[id(layer)] = (off, k2 * R * Cc)
+            tile += k2 * (-(-R // 64)) * (-(-Cc // 64))
+            off += -(-k2 * R * Cc // self.ALIGN) * self.ALIGN
+        self._tr_flat = torch.empty(max(off, 4), dtype=torch.float32, device=self.device)
+        self._tr = {k: self._tr_flat[o:o + n] for k, (o, n) in offs.items()}
+        self._tr_desc = torch.tensor(desc, dtype=torch.int32, device=self.device).contiguous()
+        self._tr_tiles = tile
+        self._tr_layers = [id(l) for l in layers]
+
+    def refresh_transposed(self, layers):
+        from . import ops
+        layers = list(layers)
+        if not layers:
+            self.tr_dirty = False
+            return
+        if getattr(self, "_tr_layers", None) != [id(l) for l in layers]:
+            self._plan_transposed(layers)
+        ops.transpose_last2_batched(self.theta, self._tr_flat, self._tr_desc, len(layers), self._tr_tiles)
         self.tr_dirty = False
 
 

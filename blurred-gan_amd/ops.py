@@ -133,6 +133,15 @@ def transpose_last2(src, dst, T, R, Cc):
     return dst
 
 
+def transpose_last2_batched(src_base, dst_base, desc, n, total_tiles):
+    """desc: int32 device tensor [n, 6] = (src_off, dst_off, T, R, C, first_tile); see include/bgan.h."""
+    _f32(src_base, dst_base)
+    assert desc.dtype == torch.int32 and desc.is_contiguous() and desc.numel() == 6 * n
+    check(_lib.load().bg_transpose_last2_batched(_ptr(src_base), _ptr(dst_base), _ptr(desc), n, total_tiles, _stream()),
+          "bg_transpose_last2_batched")
+    return dst_base
+
+
 # ------------------------------------------------------------------ dense / reductions / BN
 def gemm(A, Bm, Cm, M, N, K, transA=False, transB=False, bias=None, beta=0.0, scale=1.0):
     _f32(A, Bm, Cm, bias)

@@ -110,6 +110,10 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
                          int ksize, int stride, float beta, float scale, void* ws_d, size_t ws_bytes, void* stream);
 /* dst[t][c][r] = src[t][r][c] */
 int bg_transpose_last2(const float* src, float* dst, int T, int R, int C, void* stream);
+/* The same for every conv kernel of a network in one launch (after each optimiser step: layers.ParamStore.refresh_transposed).
+ * desc_d: n x 6 int32 on the device {src_off, dst_off, T, R, C, first_tile}: float offsets from the two bases (multiples of 4),
+ * 64x64 tiles numbered from first_tile in [t][ceil(R/64)][ceil(C/64)] order, first_tile ascending; total_tiles = their sum. */
+int bg_transpose_last2_batched(const float* src_base, float* dst_base, const int* desc_d, int n, int total_tiles, void* stream);
 
 /* ---- Dense (demo_celeba.py:55,124): row-major C[M,N] = op(A)[M,K] * op(B)[K,N] (+ bias[N]) --- */
 int bg_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, int transA, int transB,

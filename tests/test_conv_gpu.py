@@ -73,6 +73,31 @@ def test_conv_bwd_filter(B, H, W, Ci, Co, s):
     np.testing.assert_allclose(dw.cpu().numpy(), 2.5 * ref, rtol=1e-4, atol=2.5 * conv_tol(K, np.abs(ref).max()))
 
 
+def test_transpose_batched():
+    """Every conv kernel of a network transposed by one launch (float4 path and the scalar path for thin shapes)."""
+    from blurred_gan_amd import ops
+    shapes = [(25, 32, 64), (25, 3, 32), (25, 32, 3), (9, 100, 36), (25, 128, 256), (1, 4, 4)]
+    rng = np.random.default_rng(9)
+    offs, src_parts, off = [], [], 0
+    for (T, R, Cc) in shapes:
+        offs.append(off)
+        n = T * R * Cc
+        src_parts.append(rng.uniform(-1, 1, size=n))
+        off += -(-n // 4) * 4
+        src_parts.append(np.zeros(off - offs[-1] - n))
+    src = dev(np.concatenate(src_parts))
+    dst = torch.full((off,), 7.0, device="cuda")
+    desc, tile = [], 0
+    for o, (T, R, Cc) in zip(offs, shapes):
+        desc.append([o, o, T, R, Cc, tile])
+        tile += T * (-(-R // 64)) * (-(-Cc // 64))
+    ops.transpose_last2_batched(src, dst, torch.tensor(desc, dtype=torch.int32, device="cuda"), len(shapes), tile)
+    torch.cuda.synchronize()
+    for o, (T, R, Cc) in zip(offs, shapes):
+        want = src[o:o + T * R * Cc].view(T, R, Cc).permute(0, 2, 1).contiguous().view(-1)
+        assert torch.equal(dst[o:o + T * R * Cc], want), (T, R, Cc)
+
+
 def test_epilogues():
     from blurred_gan_amd import ops
     from blurred_gan_amd._lib import EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_NONE
