@@ -53,7 +53,20 @@ class Context:
             c = st.out_shape[-1]
             self.mean.append(f(c) if st.bn is not None else None)
             self.inv.append(f(c) if st.bn is not None else None)
-            self.keep.append(torch.empty((B,) + st.out_shape, dtype=torch.uint8, device=device) if st.drop else None)
+            self.keep.append(None)
+        # dropout masks of all stages live in ONE uint8 buffer (16-byte aligned slices): a pass draws them with one launch
+        sizes = [int(np.prod((B,) + st.out_shape)) if st.drop else 0 for st in net.stages]
+        offs, total = [], 0
+        for n in sizes:
+            offs.append(total)
+            total += -(-n // 16) * 16
+        self.keep_flat = torch.empty(max(total, 16), dtype=torch.uint8, device=device)
+        self.keep_total = total
+        for i, (st, n) in enumerate(zip(net.stages, sizes)):
+            if n:
+                self.keep[i] = self.keep_flat[offs[i]:offs[i] + n].view((B,) + st.out_shape)
+        rates = {float(st.drop) for st in net.stages if st.drop}
+        self.keep_rate = rates.pop() if len(rates) == 1 else None      # None: stages differ, draw per stage
         self._net, self._device = net, device
         self._extra = {}
         self.dropout_active = False
@@ -197,6 +210,11 @@ class Net:
             x = ctx.a0
         ctx.dropout_active = bool(training)
         mi = 0
+        drawn = False
+        if training and masks is None and ctx.keep_rate is not None and ctx.keep_total:
+            ops.keep_mask(ctx.keep_flat[:ctx.keep_total], 1.0 - ctx.keep_rate, seed, self.rng_offset)
+            self.rng_offset += (ctx.keep_total + 3) // 4
+            drawn = True
         for i, st in enumerate(self.stages):
             xin = x.view(B, *st.in_shape)
             ctx.xin[i] = xin
@@ -209,7 +227,7 @@ class Net:
                     keep = ctx.keep[i]
                     if masks is not None:
                         keep.copy_(masks[mi].view(keep.shape))
-                    else:
+                    elif not drawn:
                         ops.keep_mask(keep, 1.0 - st.drop, seed, self.rng_offset)
                         self.rng_offset += (keep.numel() + 3) // 4
                 mi += 1
