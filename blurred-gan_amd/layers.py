@@ -226,21 +226,33 @@ class ParamStore:
             self.v = torch.zeros_like(self.theta)
 
     def view_like(self, buf, layer, name):
-        for (l, n, off, shape, trainable) in self.entries:
-            if l is layer and n == name:
-                assert trainable
-                return buf[off:off + int(np.prod(shape))].view(shape)
-        raise KeyError(name)
+        cache = self.__dict__.setdefault("_view_cache", {})
+        key = (buf.data_ptr(), id(layer), name)
+        v = cache.get(key)
+        if v is None:
+            for (l, n, off, shape, trainable) in self.entries:
+                if l is layer and n == name:
+                    assert trainable
+                    v = cache[key] = buf[off:off + int(np.prod(shape))].view(shape)
+                    break
+            else:
+                raise KeyError(name)
+        return v
 
     def train_range(self, *layers):
         """[lo, hi) of the flat trainable buffer covered by the variables of ``layers`` (None entries ignored)."""
-        lo, hi = None, None
-        for (l, n, off, shape, trainable) in self.entries:
-            if trainable and any(l is x for x in layers if x is not None):
-                end = off + -(-int(np.prod(shape)) // self.ALIGN) * self.ALIGN
-                lo = off if lo is None else min(lo, off)
-                hi = end if hi is None else max(hi, end)
-        return (0, 0) if lo is None else (lo, hi)
+        cache = self.__dict__.setdefault("_range_cache", {})
+        key = tuple(id(x) for x in layers)
+        r = cache.get(key)
+        if r is None:
+            lo, hi = None, None
+            for (l, n, off, shape, trainable) in self.entries:
+                if trainable and any(l is x for x in layers if x is not None):
+                    end = off + -(-int(np.prod(shape)) // self.ALIGN) * self.ALIGN
+                    lo = off if lo is None else min(lo, off)
+                    hi = end if hi is None else max(hi, end)
+            r = cache[key] = (0, 0) if lo is None else (lo, hi)
+        return r
 
     def grad_of(self, layer, name):
         self.ensure_opt_state()
