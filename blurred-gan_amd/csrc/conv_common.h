@@ -159,7 +159,8 @@ __device__ inline float apply_epilogue(const P& p, float v, size_t idx, int n) {
 }
 
 // same, with the per-column operands (bias, folded BatchNorm scale) already in registers
-__device__ inline float apply_epilogue_pre(const GatherParams& p, float v, size_t idx, float bias_n, float mul_n) {
+template <class P>
+__device__ inline float apply_epilogue_pre(const P& p, float v, size_t idx, float bias_n, float mul_n) {
   if (p.epi_mode == BG_EPI_AFFINE_LRELU) {
     v = fmaf(v, mul_n, bias_n);
     return v > 0.f ? v : p.alpha * v;

@@ -260,6 +260,13 @@ __global__ __launch_bounds__(256) void conv_rows_gather_kernel(const RowGParams 
   }
   __syncthreads();
 
+  // per-column epilogue operands, once per workgroup
+  float e_bias[NT], e_mul[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    e_bias[nt] = p.bias ? p.bias[nt * 16 + li] : 0.f;
+    e_mul[nt] = p.epi_mode == BG_EPI_AFFINE_LRELU ? p.ref[nt * 16 + li] : 1.f;
+  }
   const int groups = p.Wo / (16 * TG);                       // units per output row
   const int nunits = rows * groups;
   for (int u = wave; u < nunits; u += 4) {
@@ -296,7 +303,7 @@ __global__ __launch_bounds__(256) void conv_rows_gather_kernel(const RowGParams 
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
           const size_t idx = pix * N + nt * 16 + li;
-          p.C[idx] = bg::apply_epilogue(p, acc[tg][nt][rr], idx, nt * 16 + li);
+          p.C[idx] = bg::apply_epilogue_pre(p, acc[tg][nt][rr], idx, e_bias[nt], e_mul[nt]);
         }
       }
   }
