@@ -15,7 +15,8 @@ def test_gemm_variants():
     from blurred_gan_amd import ops
     rng = np.random.default_rng(0)
     for (M, N, K, tA, tB) in [(7, 33, 10, False, False), (10, 33, 7, True, False), (5, 12, 9, False, True), (64, 1, 2048, False, False),
-                              (2048, 1, 16, True, False), (256, 8192, 100, False, False)]:
+                              (2048, 1, 16, True, False), (256, 8192, 100, False, False), (100, 8192, 256, True, False), (70, 130, 37, False, True),
+                              (33, 64, 9, True, True)]:
         A = rng.normal(size=(K, M) if tA else (M, K))
         Bm = rng.normal(size=(N, K) if tB else (K, N))
         bias = rng.normal(size=N)

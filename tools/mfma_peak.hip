@@ -90,6 +90,29 @@ __global__ __launch_bounds__(256) void mfma16_rand_loop(float* out, int iters) {
   if (s == 12345.678f) out[0] = s;
 }
 
+// bf16 pipe, random operands: the rate an fp32 product emulated with 3 x bf16 pieces (6 cross terms) would be priced against
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+template <int NACC>
+__global__ __launch_bounds__(256) void mfma_bf16_rand_loop(float* out, int iters) {
+  floatx16 acc[NACC];
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+  bf16x8 a[4], b[4];
+  const unsigned id = blockIdx.x * 256 + threadIdx.x;
+  for (int i = 0; i < 4; ++i)
+    for (int q = 0; q < 8; ++q) { a[i][q] = (__bf16)hash01(id * 64 + i * 8 + q); b[i][q] = (__bf16)hash01(id * 64 + 32 + i * 8 + q); }
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[u], b[(u + i) & 3], acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i)
+    for (int r = 0; r < 16; ++r) s += acc[i][r];
+  if (s == 12345.678f) out[0] = s;
+}
+
 template <typename F>
 static void run(const char* name, F launch, double flop_per_wg_iter, int wgs, int iters) {
   hipEvent_t e0, e1;
@@ -136,5 +159,9 @@ int main() {
       4.0 * 8 * 4 * 2.0 * 16 * 16 * 4, 1024, iters / 4);
   run("16x16x4 f32 RANDOM, 8 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma16_rand_loop<8>, dim3(g), dim3(256), 0, 0, out, it); },
       4.0 * 8 * 8 * 2.0 * 16 * 16 * 4, 1024, iters / 8);
+  run("32x32x16 bf16 RANDOM, 4 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma_bf16_rand_loop<4>, dim3(g), dim3(256), 0, 0, out, it); },
+      4.0 * 4 * 4 * 2.0 * 32 * 32 * 16, 1024, iters);
+  run("32x32x16 bf16 RANDOM, 1 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma_bf16_rand_loop<1>, dim3(g), dim3(256), 0, 0, out, it); },
+      4.0 * 4 * 1 * 2.0 * 32 * 32 * 16, 1024, iters * 4);
   return 0;
 }
