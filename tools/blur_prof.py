@@ -1,0 +1,19 @@
+import sys, os
+sys.path.insert(0, "/root/repo")
+import torch
+from blurred_gan_amd import ops
+for (shape, std) in [((128,128,128,3),5.0), ((64,256,256,3),5.0), ((64,256,256,3),23.5), ((64,256,256,3),42.34)]:
+    B,H,W,C = shape
+    ks, se, nt = ops.blur_policy(std, H, W)
+    taps = torch.tensor(ops.gauss_kernel_1d(se, ks), device="cuda")
+    x = torch.rand(*shape, device="cuda")
+    y = torch.empty_like(x)
+    tmp = torch.empty_like(x)
+    for _ in range(3): ops.blur_nhwc(x, y, taps, nt, tmp)
+    ops.prof_reset(); ops.prof_enable(True)
+    for _ in range(5): ops.blur_nhwc(x, y, taps, nt, tmp)
+    torch.cuda.synchronize()
+    recs = ops.prof_records(); ops.prof_enable(False)
+    d = {}
+    for n, ms, fl, by in recs: d.setdefault(n, []).append(ms)
+    print(shape, nt, {n: round(sum(v)/len(v)*1e3,1) for n, v in d.items()})
