@@ -177,125 +177,77 @@ __global__ __launch_bounds__(kMfmaBlurThreads) void blur_mfma_kernel(const float
 }
 
 // ------------------------------------------------------------------------------------------------
-// Images larger than 64 x 64: the same Toeplitz products as two kernels with a scratch image between them (traffic 2x
-// algorithmic), restricted to the BAND: an output block of 32 rows (columns) only contracts over the source rows (columns)
+// Images larger than 64 x 64: the same Toeplitz product, one direction per launch with a scratch image between them
+// (traffic 2x algorithmic), restricted to the BAND: an output block of 32 rows only contracts over the source rows
 // within half a kernel of it.
-//   pass H  Y[b][r][q] = sum_k  taps[k - r + half] * X[b][k][q]          q = x*C + c runs over the W*C floats of a row
-//           A = Toeplitz fragment from a zero-padded tap table in LDS, B = source rows straight from global (lanes along
-//           q: 128-B coalesced), one wave = 32 output rows x 128 columns (4 accumulators).
-//   pass W  Z[r][q] = sum_q' Y[r][q'] * S[q'][q],  S[q'][q] = taps[(q' - q)/C + half] if C divides q' - q else 0
-//           (the row is interleaved NHWC, so the W-direction Toeplitz matrix is spread out by the channel count: 1/C of the
-//           multiplies are structural zeros, paid for in exchange for never de-interleaving).  A = 32 image rows staged
-//           through LDS in chunks of 128 columns (odd row stride -> conflict-free transposed reads), B = S from a table in LDS.
-// Pays from ~100 taps up (the W pass spends C x the multiplies and stages whole chunks); below that the line kernels are used.
 // ------------------------------------------------------------------------------------------------
-constexpr int kBandCols = 128;          // output columns per wave (4 MFMA tiles)
-
-__global__ __launch_bounds__(256) void blur_band_h_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int WC,
-                                                          int units_per_img, int total_units, int col_groups, const float* __restrict__ taps, int T) {
-  extern __shared__ __attribute__((aligned(16))) float tzh[];   // [32 zeros][T][32 zeros]
+// One pass of the separable blur as  out^T = (T * in)^T : contraction along the LEADING dimension of in[R][S][C] (rows of
+// Q = S*C floats, lanes along Q -> coalesced), result stored TRANSPOSED as out[S][R][C].  Run twice it blurs both directions
+// and lands back in NHWC: x[H][W][C] -> tmp[W][H][C] -> y[H][W][C]; the W direction never needs the C-times-sparser
+// Toeplitz matrix an interleaved row would ask for.  A wave owns 32 output rows x 4 column tiles; a column tile is the
+// 32/C whole pixels that fit 32 MFMA columns, so the transposed store of one pixel column is 32*C contiguous floats.
+__global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int S, int C,
+                                                          int units_per_img, int total_units, int col_groups,
+                                                          const float* __restrict__ taps, int T) {
+  extern __shared__ __attribute__((aligned(16))) float tl[];   // [32 zeros][T][32 zeros] | per wave: 32 x 33 transpose tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = T >> 1;
-  for (int j = tid; j < T + 64; j += 256) tzh[j] = (j >= 32 && j < 32 + T) ? taps[j - 32] : 0.f;
+  const int half = T >> 1, Q = S * C;
+  float* tz = tl;
+  float* tt = tl + ((T + 64 + 3) & ~3) + wave * 32 * 33;
+  for (int j = tid; j < T + 64; j += 256) tz[j] = (j >= 32 && j < 32 + T) ? taps[j - 32] : 0.f;
   __syncthreads();
   const int unit = blockIdx.x * 4 + wave;
   if (unit >= total_units) return;
   const int b = unit / units_per_img, u = unit - b * units_per_img;
   const int rb = u / col_groups, cg = u - rb * col_groups;
-  const int r0 = rb * 32, q0 = cg * kBandCols;
+  const int PX = 32 / C, NQ = PX * C;                          // whole pixels / columns per MFMA tile
+  const int r0 = rb * 32, s0 = cg * 4 * PX;                    // first output row, first pixel column of this wave
   const int li = lane & 31, kk = lane >> 5;
-  const float* xi = x + (size_t)b * H * WC;
-  float* yi = y + (size_t)b * H * WC;
+  const float* xi = x + (size_t)b * R * Q;
+  float* yi = y + (size_t)b * R * Q;
   floatx16 acc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-  const int k_lo = max(0, r0 - half) & ~1, k_hi = min(H, r0 + 32 + half);
-  const float* ta = tzh + 32 + half - (r0 + li) + kk;          // + k
+  const int k_lo = max(0, r0 - half) & ~1, k_hi = min(R, r0 + 32 + half);
+  const float* ta = tz + 32 + half - (r0 + li) + kk;           // + k
   bool cok[4];
+  int qcol[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) cok[j] = q0 + 32 * j + li < WC;
-  for (int k = k_lo; k < k_hi; k += 2) {
+  for (int j = 0; j < 4; ++j) {
+    qcol[j] = (s0 + j * PX) * C + li;
+    cok[j] = li < NQ && qcol[j] < Q;
+  }
+  float bv[4], bn[4];
+  auto bload = [&](int k, float (&v)[4]) {
     const int ks = k + kk;
+    const float* xr = xi + (size_t)ks * Q;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = (k < k_hi && ks < R && cok[j]) ? xr[qcol[j]] : 0.f;
+  };
+  bload(k_lo, bv);
+  for (int k = k_lo; k < k_hi; k += 2) {
+    bload(k + 2, bn);                                          // next k-pair's source values fly under this pair's MFMAs
     const float a = ta[k];
-    const float* xr = xi + (size_t)ks * WC + q0 + li;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float bv = (ks < H && cok[j]) ? xr[32 * j] : 0.f;
-      acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv, acc[j], 0, 0, 0);
-    }
+    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[j], 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bv[j] = bn[j];
   }
+  // transposed store: tile element (r, q = pixel*C + c) -> out[(pixel*R + r)*C + c]; through this wave's LDS tile so that the
+  // 32*C floats of one pixel column leave contiguously
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    if (!cok[j]) continue;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int r = r0 + (q & 3) + 8 * (q >> 2) + 4 * kk;
-      if (r < H) yi[(size_t)r * WC + q0 + 32 * j + li] = acc[j][q];
-    }
-  }
-}
-
-__global__ __launch_bounds__(256) void blur_band_w_kernel(const float* __restrict__ x, float* __restrict__ y, int rows_total, int WC, int C,
-                                                          int col_groups_wg, const float* __restrict__ taps, int T) {
-  extern __shared__ __attribute__((aligned(16))) float lw[];
-  constexpr int CH = 128, AS = CH + 1;                         // K chunk staged per step, odd row stride
-  const int half = T >> 1, halfC = half * C;
-  const int P3 = halfC + 256;                                  // table covers q' - q in [-P3, P3] (band + a partial chunk either side)
-  float* tz3 = lw;                                             // [2*P3 + 1]
-  float* As = lw + ((2 * P3 + 1 + 3) & ~3);                    // [32][AS]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int j = tid; j < 2 * P3 + 1; j += 256) {
-    const int d = j - P3;                                      // q' - q
-    float v = 0.f;
-    if (d % C == 0) {
-      const int t = d / C + half;
-      if (t >= 0 && t < T) v = taps[t];
-    }
-    tz3[j] = v;
-  }
-  const int rb = blockIdx.x / col_groups_wg, cgw = blockIdx.x - rb * col_groups_wg;
-  const int r0 = rb * 32;
-  const int qw0 = cgw * 4 * kBandCols + wave * kBandCols;      // this wave's first output column
-  const int li = lane & 31, kk = lane >> 5;
-  floatx16 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-  // K range of the whole workgroup (4 waves x 128 columns), in chunks of CH source columns
-  const int wg_q0 = cgw * 4 * kBandCols;
-  const int k_lo = max(0, wg_q0 - halfC) / CH * CH, k_hi = min(WC, wg_q0 + 4 * kBandCols + halfC);
-  const int my_lo = qw0 - halfC, my_hi = qw0 + kBandCols + halfC;   // this wave's band
-  const bool wave_live = qw0 < WC;
-  for (int c0 = k_lo; c0 < k_hi; c0 += CH) {
-    __syncthreads();
-    for (int e = tid; e < 32 * CH; e += 256) {
-      const int rr = e / CH, cc = e - rr * CH;
-      const int r = r0 + rr, q = c0 + cc;
-      As[rr * AS + cc] = (r < rows_total && q < WC) ? x[(size_t)r * WC + q] : 0.f;
-    }
-    __syncthreads();
-    if (!wave_live || c0 + CH <= my_lo || c0 >= my_hi) continue;      // chunk outside this wave's band (uniform per wave)
-    const float* aa = As + li * AS + kk;
-    const float* tb = tz3 + P3 + (c0 + kk) - (qw0 + li);         // + 2*kp - 32*j
-#pragma unroll 4
-    for (int kp = 0; kp < CH / 2; ++kp) {
-      const float a = aa[2 * kp];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, tb[2 * kp - 32 * j], acc[j], 0, 0, 0);
-    }
-  }
-  if (!wave_live) return;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int q = qw0 + 32 * j + li;
-    if (q >= WC) continue;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      const int r = r0 + (e & 3) + 8 * (e >> 2) + 4 * kk;
-      if (r < rows_total) y[(size_t)r * WC + q] = acc[j][e];
+    for (int q = 0; q < 16; ++q) tt[((q & 3) + 8 * (q >> 2) + 4 * kk) * 33 + li] = acc[j][q];
+    // same wave writes and reads: LDS executes a wave's operations in order
+    const int nrow = min(32, R - r0);
+    for (int e = lane; e < PX * 32 * C; e += 64) {
+      const int px = e / (32 * C), rem = e - px * 32 * C;
+      const int r = rem / C, c = rem - r * C;
+      const int sp = s0 + j * PX + px;
+      if (sp < S && r < nrow) yi[((size_t)sp * R + r0 + r) * C + c] = tt[r * 33 + px * C + c];
     }
   }
 }
@@ -515,25 +467,25 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
              (size_t)H * W * C * 4);
   const int WC = W * C;
   {
-    static const int band_min_taps = getenv("BG_BLUR_BAND_MIN_TAPS") ? atoi(getenv("BG_BLUR_BAND_MIN_TAPS")) : 100;   // measured on 256x256x3: 31 taps 0.26 ms vs 0.17 (line kernels), 143 taps 0.39 vs 0.47, 255 taps 0.44 vs 0.67
-    const int half = n_taps / 2;
-    const size_t lds_bw = ((size_t)((2 * (half * C + 256) + 1 + 3) & ~3) + 32 * 129) * sizeof(float);
-    if (n_taps >= band_min_taps && lds_bw <= 64 * 1024 && (size_t)B * H * WC < (1ull << 31)) {
-      const int cg = (int)bg::cdiv(WC, kBandCols), rbs = (int)bg::cdiv(H, 32);
-      const int units_per_img = rbs * cg;
-      {
-        bg::Launch L(stream, "blur_band_h", flops / 2, bytes);
-        hipLaunchKernelGGL(blur_band_h_kernel, dim3((unsigned)bg::cdiv((size_t)units_per_img * B, 4), 1, 1), dim3(256),
-                           (n_taps + 64) * sizeof(float), s, x, tmp_d, H, WC, units_per_img, units_per_img * B, cg, taps_d, n_taps);
-        int rc = L.done("blur_band_h_kernel");
+    // two transposing banded-Toeplitz passes on the matrix cores: x[H][W][C] -> tmp[W][H][C] -> y[H][W][C].
+    // measured (64 x 256x256x3): 31 / 143 / 255 taps 0.13 / 0.21 / 0.26 ms against 0.17 / 0.47 / 0.67 for the line kernels;
+    // 128x128 at 31 taps 0.089 against 0.069 -> line kernels keep the small-image, narrow-kernel corner.
+    static const int band_t_min = getenv("BG_BLUR_BANDT_MIN_TAPS") ? atoi(getenv("BG_BLUR_BANDT_MIN_TAPS")) : 48;
+    const bool big = H >= 192 && W >= 192;
+    if ((n_taps >= band_t_min || (big && n_taps >= 13)) && C <= 32 && (size_t)B * H * WC < (1ull << 31)) {
+      const int PX = 32 / C;
+      const size_t lds_t = ((size_t)((n_taps + 64 + 3) & ~3) + 4 * 32 * 33) * sizeof(float);
+      for (int pass = 0; pass < 2; ++pass) {
+        const int R = pass == 0 ? H : W, S = pass == 0 ? W : H;
+        const int cg = (int)bg::cdiv(S, 4 * PX), rbs = (int)bg::cdiv(R, 32);
+        const int units_per_img = rbs * cg;
+        bg::Launch L(stream, pass == 0 ? "blur_band_t1" : "blur_band_t2", flops / 2, bytes);
+        hipLaunchKernelGGL(blur_band_t_kernel, dim3((unsigned)bg::cdiv((size_t)units_per_img * B, 4)), dim3(256), lds_t, s,
+                           pass == 0 ? x : tmp_d, pass == 0 ? tmp_d : y, R, S, C, units_per_img, units_per_img * B, cg, taps_d, n_taps);
+        int rc = L.done("blur_band_t_kernel");
         if (rc) return rc;
       }
-      const int rows_total = B * H;
-      const int cgw = (int)bg::cdiv(WC, 4 * kBandCols);
-      bg::Launch L(stream, "blur_band_w", flops / 2, bytes);
-      hipLaunchKernelGGL(blur_band_w_kernel, dim3((unsigned)(bg::cdiv(rows_total, 32) * cgw)), dim3(256), lds_bw, s, tmp_d, y, rows_total, WC, C, cgw,
-                         taps_d, n_taps);
-      return L.done("blur_band_w_kernel");
+      return BG_OK;
     }
   }
   const size_t lds_h = ((size_t)H * kStripW + n_taps + kR + 4) * sizeof(float);
