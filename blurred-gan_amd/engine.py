@@ -168,7 +168,26 @@ class Net:
             ks, se, nt = ops.blur_policy(std, H, W)
             taps = ops.gauss_kernel_1d(se, ks)
             assert len(taps) == nt
-            t = torch.tensor(taps, dtype=torch.float32, device=self.device)
+            # sigma changes every batch under BlurDecayController: upload without stalling the host (a pageable copy waits
+            # for the stream to drain and the GPU then idles until the host has caught up) -- pinned staging ring, async copy
+            ring = self.__dict__.setdefault("_taps_ring", {"i": 0, "bufs": [], "evs": []})
+            if not ring["bufs"]:
+                for _ in range(8):
+                    ring["bufs"].append(torch.empty(1024, dtype=torch.float32, pin_memory=True))
+                    ring["evs"].append(None)
+            i = ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
+            if ring["evs"][i] is not None:
+                ring["evs"][i].synchronize()                  # slot re-used 8 uploads later: normally long complete
+            if nt <= 1024:
+                host = ring["bufs"][i][:nt]
+                host.copy_(torch.tensor(taps, dtype=torch.float32))
+                t = torch.empty(nt, dtype=torch.float32, device=self.device)
+                t.copy_(host, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                ring["evs"][i] = ev
+            else:
+                t = torch.tensor(taps, dtype=torch.float32, device=self.device)
             if len(self._taps_cache) > 64:
                 self._taps_cache.clear()
             hit = self._taps_cache[key] = (t, nt)
