@@ -835,6 +835,11 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     p.a_bytes = (unsigned)a_bytes;
     p.w_bytes = (unsigned)w_bytes;
     snprintf(name, sizeof name, "conv_igemm_%s", tag);
+    {
+      int taken = 0;
+      const int rc = bg::try_conv_x6(p, stream, name, &taken);   // experiment, off unless BGAN_CONV_MATH=bf16x6
+      if (rc || taken) return rc;
+    }
     static const int force_bk = getenv("BG_IGEMM_BK") ? atoi(getenv("BG_IGEMM_BK")) : 0;   // tuning aid
     return (p.Ck % 32 == 0 && force_bk != 16) ? dispatch_igemm<32>(p, epi, stream, name) : dispatch_igemm<16>(p, epi, stream, name);
   }
