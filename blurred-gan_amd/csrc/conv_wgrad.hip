@@ -149,30 +149,45 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
     for (int i = 0; i < BP; ++i) b_off[i] = (unsigned)((brow + i * RPP_B) * HoWo * p.Co * 4 + b_coloff);
   }
   int s_m0 = m_begin;                                       // chunk origin of the NEXT gload (wave-uniform)
-  // P2 == 2: is the chunk starting at logical pixel m0 inside the image for this workgroup's tap?
-  auto chunk_live = [&](int m0) {
-    const int pos = m0 >> p.lg_b;
-    const int oh = pos >> p.lg_w, ow = pos & (p.Wo - 1);
-    return m0 < m_end && (unsigned)(oh * p.s + dyk) < (unsigned)p.H && (unsigned)(ow * p.s + dxk) < (unsigned)p.W;
-  };
+  // P2 == 2 (position-major): only the chunks whose output position is inside the image for this tap are visited.  They
+  // form a rectangle of positions x (B / BKP) image chunks; the rectangle's chunk list is cut evenly over the ksplit
+  // workgroups of this (tile, tap), so corner taps (a quarter of the positions live) and centre taps stay balanced.
+  int q_oh = 0, q_ow = 0, q_bc = 0, q_left = 0, q_ow_lo = 0, q_ow_hi = 0, q_nb = 1;
+  int nsteps_live = 0;
+  if (P2 == 2) {
+    const int oh_lo = max(0, (-dyk + p.s - 1) / p.s), oh_hi = min(p.Ho - 1, (p.H - 1 - dyk) / p.s);
+    const int ow_lo = max(0, (-dxk + p.s - 1) / p.s), ow_hi = min(p.Wo - 1, (p.W - 1 - dxk) / p.s);
+    const int rh = max(0, oh_hi - oh_lo + 1), rw = max(0, ow_hi - ow_lo + 1);
+    q_nb = p.B / BKP;
+    const int nlive = rh * rw * q_nb;
+    const int cpz = (nlive + p.ksplit - 1) / p.ksplit;
+    const int q_begin = min(nlive, zsplit * cpz), q_end = min(nlive, q_begin + cpz);
+    nsteps_live = q_end - q_begin;
+    q_left = nsteps_live;
+    const int pi = q_begin / q_nb;
+    q_bc = q_begin - pi * q_nb;
+    q_oh = oh_lo + (rw > 0 ? pi / rw : 0);
+    q_ow = ow_lo + (rw > 0 ? pi % rw : 0);
+    q_ow_lo = ow_lo; q_ow_hi = ow_hi;
+  }
 
   auto gload = [&](int) {     // loads the NEXT chunk in sequence (called once per step, in order)
     if (P2 == 2) {
-      const int m0 = __builtin_amdgcn_readfirstlane(s_m0);
-      s_m0 = m0 + BKP;
-      if (chunk_live(m0)) {                                  // wave-uniform: dead chunks issue no loads at all
-        const int pos = m0 >> p.lg_b, b0 = m0 & (p.B - 1);
-        const int oh = pos >> p.lg_w, ow = pos & (p.Wo - 1);
-        const unsigned offS = (unsigned)(((b0 * p.H + oh * p.s + dyk) * p.W + ow * p.s + dxk) * p.Ci * 4);
+      if (q_left > 0) {                                      // wave-uniform
+        const int b0 = q_bc * BKP, pos = q_oh * p.Wo + q_ow;
+        const unsigned offS = (unsigned)(((b0 * p.H + q_oh * p.s + dyk) * p.W + q_ow * p.s + dxk) * p.Ci * 4);
         const unsigned offY = (unsigned)((b0 * HoWo + pos) * p.Co * 4);
-        const int left = m_end - m0;
 #pragma unroll
         for (int i = 0; i < AP; ++i)
-          regA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (a_col_ok && t_r[i] < left) ? t_off[i] + offS : kOob, 0, 0));
+          regA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, a_col_ok ? t_off[i] + offS : kOob, 0, 0));
 #pragma unroll
         for (int i = 0; i < BP; ++i)
-          regB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
-              rsY, (b_col_ok && brow + i * RPP_B < left) ? b_off[i] + offY : kOob, 0, 0));
+          regB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, b_col_ok ? b_off[i] + offY : kOob, 0, 0));
+        --q_left;
+        if (++q_bc == q_nb) {
+          q_bc = 0;
+          if (++q_ow > q_ow_hi) { q_ow = q_ow_lo; ++q_oh; }
+        }
       }
       return;
     }
@@ -244,21 +259,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
   constexpr int PF = (MI * NI >= 4) ? 1 : (MI * NI >= 2 ? 2 : 4);   // k-pairs per fragment group: >= 4 MFMAs behind every LDS wait
   constexpr int NG = ITERS / PF;
   static_assert(ITERS % PF == 0 && NG >= 2, "fragment grouping");
-  for (int step = 0; step < nsteps; ++step) {
+  const int nsteps_run = P2 == 2 ? nsteps_live : nsteps;
+  for (int step = 0; step < nsteps_run; ++step) {
     const int cur = step & 1;
     const float* sa = sa0 + cur * STAGE;
     const float* sb = sb0 + cur * STAGE;
-    if (P2 == 2) {
-      // uniform skips: a dead chunk costs one barrier; its neighbours still get their ds_write / loads
-      const int mc = m_begin + step * BKP;
-      const bool live_cur = chunk_live(mc), live_next = chunk_live(mc + BKP);
-      if (!live_cur) {
-        if (live_next) lstore(cur ^ 1);
-        gload(step + 2);
-        __syncthreads();
-        continue;
-      }
-    }
     // Fragment groups are fetched one group ahead of the MFMAs that consume them (register double buffer); the
     // sched_barrier pins that order -- left alone, the scheduler sinks each ds_read to just before its MFMA and
     // the LDS latency is exposed once per k-pair.
@@ -279,7 +284,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
       const int c = grp & 1;
       if (grp + 1 < NG) fetch(c ^ 1, grp + 1);
       if (grp == NG / 2) {
-        if (P2 != 2 || chunk_live(m_begin + (step + 1) * BKP)) lstore(cur ^ 1);
+        lstore(cur ^ 1);
         gload(step + 2);
       }
       __builtin_amdgcn_sched_barrier(0);
