@@ -184,24 +184,29 @@ __global__ __launch_bounds__(kMfmaBlurThreads) void blur_mfma_kernel(const float
 // One pass of the separable blur as  out^T = (T * in)^T : contraction along the LEADING dimension of in[R][S][C] (rows of
 // Q = S*C floats, lanes along Q -> coalesced), result stored TRANSPOSED as out[S][R][C].  Run twice it blurs both directions
 // and lands back in NHWC: x[H][W][C] -> tmp[W][H][C] -> y[H][W][C]; the W direction never needs the C-times-sparser
-// Toeplitz matrix an interleaved row would ask for.  A wave owns 32 output rows x 4 column tiles; a column tile is the
-// 32/C whole pixels that fit 32 MFMA columns, so the transposed store of one pixel column is 32*C contiguous floats.
-__global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int S, int C,
-                                                          int units_per_img, int total_units, int col_groups,
-                                                          const float* __restrict__ taps, int T) {
-  extern __shared__ __attribute__((aligned(16))) float tl[];   // [32 zeros][T][32 zeros] | per wave: 32 x 33 transpose tile
+// Toeplitz matrix an interleaved row would ask for.
+// Workgroup = 128 output rows (one 32-row block per wave) x 4 column tiles; a column tile is the 32/C whole pixels that fit 32
+// MFMA columns, so the transposed store of one pixel column is 32*C contiguous floats.  Source rows stream through LDS in chunks
+// of 32 (float4 loads, double-buffered, shared by the four waves: every source element is fetched once per workgroup); a wave
+// skips the chunks outside its own band.
+constexpr int kBtRows = 128, kBtChunk = 32, kBtStride = 132, kBtPad = 64;
+
+template <int C>        // channel count as a compile-time constant: every index division below is by a constant
+__global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int S,
+                                                          int row_groups, int col_groups, const float* __restrict__ taps, int T) {
+  extern __shared__ __attribute__((aligned(16))) float tl[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = T >> 1, Q = S * C;
-  float* tz = tl;
-  float* tt = tl + ((T + 64 + 3) & ~3) + wave * 32 * 33;
-  for (int j = tid; j < T + 64; j += 256) tz[j] = (j >= 32 && j < 32 + T) ? taps[j - 32] : 0.f;
-  __syncthreads();
-  const int unit = blockIdx.x * 4 + wave;
-  if (unit >= total_units) return;
-  const int b = unit / units_per_img, u = unit - b * units_per_img;
-  const int rb = u / col_groups, cg = u - rb * col_groups;
-  const int PX = 32 / C, NQ = PX * C;                          // whole pixels / columns per MFMA tile
-  const int r0 = rb * 32, s0 = cg * 4 * PX;                    // first output row, first pixel column of this wave
+  float* tz = tl;                                              // [64 zeros][T][64 zeros]
+  float* Bs = tl + ((T + 2 * kBtPad + 3) & ~3);                // [2][32][132] source chunks; later 4 x [32][33] transpose tiles
+  for (int j = tid; j < T + 2 * kBtPad; j += 256) tz[j] = (j >= kBtPad && j < kBtPad + T) ? taps[j - kBtPad] : 0.f;
+  const int per_img = row_groups * col_groups;
+  const int b = blockIdx.x / per_img, u = blockIdx.x - b * per_img;
+  const int rg = u / col_groups, cg = u - rg * col_groups;
+  constexpr int PX = 32 / C, NQ = PX * C;                      // whole pixels / columns per MFMA tile
+  const int r0 = rg * kBtRows, s0 = cg * 4 * PX;
+  const int q0 = s0 * C, ncols = min(4 * NQ, Q - q0);          // this workgroup's source / output columns
+  const int rw0 = r0 + 32 * wave;                              // this wave's first output row
   const int li = lane & 31, kk = lane >> 5;
   const float* xi = x + (size_t)b * R * Q;
   float* yi = y + (size_t)b * R * Q;
@@ -210,44 +215,73 @@ __global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restric
   for (int j = 0; j < 4; ++j)
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-  const int k_lo = max(0, r0 - half) & ~1, k_hi = min(R, r0 + 32 + half);
-  const float* ta = tz + 32 + half - (r0 + li) + kk;           // + k
-  bool cok[4];
-  int qcol[4];
+  const int k_lo = max(0, r0 - half) / kBtChunk * kBtChunk, k_hi = min(R, r0 + kBtRows + half);
+  const int my_lo = rw0 - half, my_hi = rw0 + 32 + half;      // source rows this wave's block needs
+  const bool vec4 = (Q & 3) == 0 && (ncols & 3) == 0;
+  // chunk loader: 32 rows x ncols floats, row-contiguous in global memory
+  float4 g[4];
+  auto gload = [&](int kc) {
+    if (vec4) {
+      const int nq4 = ncols >> 2;
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    qcol[j] = (s0 + j * PX) * C + li;
-    cok[j] = li < NQ && qcol[j] < Q;
-  }
-  float bv[4], bn[4];
-  auto bload = [&](int k, float (&v)[4]) {
-    const int ks = k + kk;
-    const float* xr = xi + (size_t)ks * Q;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) v[j] = (k < k_hi && ks < R && cok[j]) ? xr[qcol[j]] : 0.f;
+      for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256, rr = e / 32, c4 = e - rr * 32;            // 32 float4 slots per row (128 columns)
+        const int k = kc + rr;
+        g[i] = (rr < kBtChunk && c4 < nq4 && k < R) ? *reinterpret_cast<const float4*>(xi + (size_t)k * Q + q0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
   };
-  bload(k_lo, bv);
-  for (int k = k_lo; k < k_hi; k += 2) {
-    bload(k + 2, bn);                                          // next k-pair's source values fly under this pair's MFMAs
-    const float a = ta[k];
+  auto lstore = [&](int buf, int kc) {
+    float* d = Bs + buf * kBtChunk * kBtStride;
+    if (vec4) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bv[j], acc[j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i) {
+        const int e = tid + i * 256, rr = e / 32, c4 = e - rr * 32;
+        if (rr < kBtChunk) *reinterpret_cast<float4*>(d + rr * kBtStride + 4 * c4) = g[i];
+      }
+    } else {
+      for (int e = tid; e < kBtChunk * 128; e += 256) {
+        const int rr = e >> 7, c = e & 127;
+        const int k = kc + rr;
+        d[rr * kBtStride + c] = (c < ncols && k < R) ? xi[(size_t)k * Q + q0 + c] : 0.f;
+      }
+    }
+  };
+  gload(k_lo);
+  lstore(0, k_lo);
+  __syncthreads();
+  const float* ta = tz + kBtPad + half - (rw0 + li) + kk;      // + k
+  int buf = 0;
+  for (int kc = k_lo; kc < k_hi; kc += kBtChunk, buf ^= 1) {
+    const bool more = kc + kBtChunk < k_hi;
+    if (more) gload(kc + kBtChunk);                            // next chunk's loads fly under this chunk's MFMAs
+    if (rw0 < R && kc + kBtChunk > my_lo && kc < my_hi) {      // wave-uniform: chunk inside this wave's band
+      const float* bb = Bs + buf * kBtChunk * kBtStride + kk * kBtStride + li;
+#pragma unroll 4
+      for (int kp = 0; kp < kBtChunk / 2; ++kp) {
+        const float a = ta[kc + 2 * kp];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bv[j] = bn[j];
+        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[2 * kp * kBtStride + j * NQ], acc[j], 0, 0, 0);
+      }
+    }
+    if (more) lstore(buf ^ 1, kc + kBtChunk);
+    __syncthreads();
   }
-  // transposed store: tile element (r, q = pixel*C + c) -> out[(pixel*R + r)*C + c]; through this wave's LDS tile so that the
-  // 32*C floats of one pixel column leave contiguously
+  // transposed store: tile element (r, q = pixel*C + c) -> out[(pixel*R + r)*C + c]; through this wave's LDS tile (the chunk
+  // buffers are free after the last barrier) so that the 32*C floats of one pixel column leave contiguously
+  float* tt = Bs + wave * 32 * 33;
+  if (rw0 >= R) return;
+  const int nrow = min(32, R - rw0);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
 #pragma unroll
     for (int q = 0; q < 16; ++q) tt[((q & 3) + 8 * (q >> 2) + 4 * kk) * 33 + li] = acc[j][q];
     // same wave writes and reads: LDS executes a wave's operations in order
-    const int nrow = min(32, R - r0);
     for (int e = lane; e < PX * 32 * C; e += 64) {
       const int px = e / (32 * C), rem = e - px * 32 * C;
       const int r = rem / C, c = rem - r * C;
       const int sp = s0 + j * PX + px;
-      if (sp < S && r < nrow) yi[((size_t)sp * R + r0 + r) * C + c] = tt[r * 33 + px * C + c];
+      if (sp < S && r < nrow) yi[((size_t)sp * R + rw0 + r) * C + c] = tt[r * 33 + px * C + c];
     }
   }
 }
@@ -472,16 +506,22 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
     // 128x128 at 31 taps 0.089 against 0.069 -> line kernels keep the small-image, narrow-kernel corner.
     static const int band_t_min = getenv("BG_BLUR_BANDT_MIN_TAPS") ? atoi(getenv("BG_BLUR_BANDT_MIN_TAPS")) : 48;
     const bool big = H >= 192 && W >= 192;
-    if ((n_taps >= band_t_min || (big && n_taps >= 13)) && C <= 32 && (size_t)B * H * WC < (1ull << 31)) {
+    if ((n_taps >= band_t_min || (big && n_taps >= 13)) && C <= 4 && (size_t)B * H * WC < (1ull << 31)) {
       const int PX = 32 / C;
-      const size_t lds_t = ((size_t)((n_taps + 64 + 3) & ~3) + 4 * 32 * 33) * sizeof(float);
+      const size_t lds_t = ((size_t)((n_taps + 2 * kBtPad + 3) & ~3) + 2 * kBtChunk * kBtStride) * sizeof(float);
       for (int pass = 0; pass < 2; ++pass) {
         const int R = pass == 0 ? H : W, S = pass == 0 ? W : H;
-        const int cg = (int)bg::cdiv(S, 4 * PX), rbs = (int)bg::cdiv(R, 32);
-        const int units_per_img = rbs * cg;
+        const int cg = (int)bg::cdiv(S, 4 * PX), rgs = (int)bg::cdiv(R, kBtRows);
         bg::Launch L(stream, pass == 0 ? "blur_band_t1" : "blur_band_t2", flops / 2, bytes);
-        hipLaunchKernelGGL(blur_band_t_kernel, dim3((unsigned)bg::cdiv((size_t)units_per_img * B, 4)), dim3(256), lds_t, s,
-                           pass == 0 ? x : tmp_d, pass == 0 ? tmp_d : y, R, S, C, units_per_img, units_per_img * B, cg, taps_d, n_taps);
+        const dim3 grid((unsigned)((size_t)B * rgs * cg));
+        const float* src = pass == 0 ? x : tmp_d;
+        float* dst = pass == 0 ? tmp_d : y;
+        switch (C) {
+          case 1: hipLaunchKernelGGL(blur_band_t_kernel<1>, grid, dim3(256), lds_t, s, src, dst, R, S, rgs, cg, taps_d, n_taps); break;
+          case 2: hipLaunchKernelGGL(blur_band_t_kernel<2>, grid, dim3(256), lds_t, s, src, dst, R, S, rgs, cg, taps_d, n_taps); break;
+          case 3: hipLaunchKernelGGL(blur_band_t_kernel<3>, grid, dim3(256), lds_t, s, src, dst, R, S, rgs, cg, taps_d, n_taps); break;
+          default: hipLaunchKernelGGL(blur_band_t_kernel<4>, grid, dim3(256), lds_t, s, src, dst, R, S, rgs, cg, taps_d, n_taps); break;
+        }
         int rc = L.done("blur_band_t_kernel");
         if (rc) return rc;
       }
