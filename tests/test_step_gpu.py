@@ -34,7 +34,9 @@ def _make(arch, B, std, seed=0, gbs=None, **kw):
     return gan, st, reals, rng
 
 
-@pytest.mark.parametrize("arch,B,std", [("tiny", 4, 0.05), ("tiny", 5, 1.2), ("tiny_mnist", 4, 0.7), ("mnist", 3, 0.05)])
+@pytest.mark.parametrize("arch,B,std", [("tiny", 4, 0.05), ("tiny", 5, 1.2), ("tiny_mnist", 4, 0.7), ("mnist", 3, 0.05),
+                                        ("celeba64", 2, 1.0), ("celeba128", 2, 2.0),      # the headline architectures, every layer shape of C2 / C4
+                                        ("celeba64", 64, 5.0)])     # ... and at a batch that takes the position-major / tap-skipping / split-K paths
 def test_gradients_match_oracle(arch, B, std):
     gan, st, reals, rng = _make(arch, B, std, gbs=B + 1)
     rnd = S.draw_randomness(arch, B, rng, np.float64)
@@ -52,9 +54,13 @@ def test_gradients_match_oracle(arch, B, std):
         np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=2e-4 * scale)
     gg, upd, gm = S.generator_grads(st, rnd, hp, B)
     pgg = product_grads(gan.generator)
+    # Generator gradients pass through five BatchNorm backwards (dz - mean(dz) - xhat*mean(dz*xhat)): at batch 64 the
+    # cancellation leaves gradients of 1e-5 whose fp32 evaluation is itself only good to ~1e-2 of their maximum -- the ORACLE
+    # run in float32 deviates from its float64 run by 5e-4...1.4e-2 on this case (the HIP path: 1e-4...3e-3).
+    g_atol = 1e-2 if B >= 64 else 2e-4
     for a, b in zip(pgg, oracle_grad_list(gg)):
         scale = max(np.abs(b).max(), 1e-6)
-        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=2e-4 * scale)
+        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=g_atol * scale)
     np.testing.assert_allclose(gan.images[0].cpu().numpy(), fakes, rtol=1e-4, atol=1e-5)
     for k in ("real_scores", "disc_loss", "gp_term", "norm_term"):
         assert abs(got[k] - met[k]) < 1e-4 * max(1, abs(met[k])), (k, got[k], met[k])
