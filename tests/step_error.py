@@ -1,8 +1,8 @@
 """Per-layer gradient error of one product step against the fp64 oracle (max |err| / max |ref| per variable).
-Usage: python tools/step_error.py [arch] [B] [std]"""
+Usage: python tests/step_error.py [arch] [B] [std]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import numpy as np
 from oracle import step as S
 import test_step_gpu as T

@@ -1,5 +1,5 @@
 """Error of the conv forward / data gradient against an fp64 reference, for whichever arithmetic BGAN_CONV_MATH selects.
-Run twice:  python tools/x6_accuracy.py   and   BGAN_CONV_MATH=bf16x6 python tools/x6_accuracy.py"""
+Run twice:  python tests/x6_accuracy.py   and   BGAN_CONV_MATH=bf16x6 python tests/x6_accuracy.py"""
 import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
