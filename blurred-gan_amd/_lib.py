@@ -15,7 +15,8 @@ class BgError(RuntimeError):
 
 class Epilogue(C.Structure):
     _fields_ = [("mode", C.c_int), ("bias", C.c_void_p), ("ref", C.c_void_p), ("keep", C.c_void_p),
-                ("alpha", C.c_float), ("scale", C.c_float), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t)]
+                ("alpha", C.c_float), ("scale", C.c_float), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
+                ("keep_elems", C.c_size_t)]
 
 
 EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_AFFINE_LRELU = 0, 1, 2, 3, 4

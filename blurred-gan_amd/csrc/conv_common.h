@@ -43,6 +43,7 @@ struct GatherParams {
   const float* bias;
   const float* ref;
   const uint8_t* keep;
+  size_t keep_elems;   // the mask covers output elements [0, keep_elems); 0 = all
   float alpha, scale;
   GatherPhase ph[kMaxPhases];
 };
@@ -141,11 +142,11 @@ __device__ inline float apply_epilogue(const P& p, float v, size_t idx, int n) {
   switch (p.epi_mode) {
     case BG_EPI_BIAS_LRELU:
       v = v > 0.f ? v : p.alpha * v;
-      if (p.keep) v = p.keep[idx] ? v * p.scale : 0.f;
+      if (p.keep && (p.keep_elems == 0 || idx < p.keep_elems)) v = p.keep[idx] ? v * p.scale : 0.f;
       break;
     case BG_EPI_MUL_GRAD: {
       float f = p.ref[idx] > 0.f ? 1.f : p.alpha;
-      if (p.keep) f = p.keep[idx] ? f * p.scale : 0.f;
+      if (p.keep && (p.keep_elems == 0 || idx < p.keep_elems)) f = p.keep[idx] ? f * p.scale : 0.f;
       v *= f;
       break;
     }
@@ -169,11 +170,11 @@ __device__ inline float apply_epilogue_pre(const P& p, float v, size_t idx, floa
   switch (p.epi_mode) {
     case BG_EPI_BIAS_LRELU:
       v = v > 0.f ? v : p.alpha * v;
-      if (p.keep) v = p.keep[idx] ? v * p.scale : 0.f;
+      if (p.keep && (p.keep_elems == 0 || idx < p.keep_elems)) v = p.keep[idx] ? v * p.scale : 0.f;
       break;
     case BG_EPI_MUL_GRAD: {
       float f = p.ref[idx] > 0.f ? 1.f : p.alpha;
-      if (p.keep) f = p.keep[idx] ? f * p.scale : 0.f;
+      if (p.keep && (p.keep_elems == 0 || idx < p.keep_elems)) f = p.keep[idx] ? f * p.scale : 0.f;
       v *= f;
       break;
     }

@@ -824,10 +824,10 @@ int dispatch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const 
 }
 
 int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char* tag) {
-  p.epi_mode = BG_EPI_NONE; p.bias = nullptr; p.ref = nullptr; p.keep = nullptr; p.alpha = 0.3f; p.scale = 1.f;
+  p.epi_mode = BG_EPI_NONE; p.bias = nullptr; p.ref = nullptr; p.keep = nullptr; p.keep_elems = 0; p.alpha = 0.3f; p.scale = 1.f;
   p.ksplit = 1; p.slab = nullptr;
   if (epi) {
-    p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep;
+    p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep; p.keep_elems = epi->keep_elems;
     p.alpha = epi->alpha; p.scale = epi->scale;
     BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "%s: epilogue mode %d", tag, epi->mode);
     BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || epi->ref, BG_ERR_NULL, "%s: BG_EPI_MUL_GRAD needs ref", tag);

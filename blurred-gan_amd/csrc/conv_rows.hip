@@ -35,6 +35,7 @@ struct RowParams {
   const float* bias;
   const float* ref;
   const unsigned char* keep;
+  size_t keep_elems;
   float alpha, scale;
 };
 
@@ -212,6 +213,7 @@ struct RowGParams {
   const float* bias;
   const float* ref;
   const unsigned char* keep;
+  size_t keep_elems;
   float alpha, scale;
 };
 
@@ -357,7 +359,7 @@ int try_conv_rows_gather(int bwd_data, const float* a, const float* w, float* c,
     BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "conv rows: epilogue mode %d", epi->mode);
     BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || epi->ref, BG_ERR_NULL, "conv rows: BG_EPI_MUL_GRAD needs ref");
     BG_REQUIRE(epi->mode != BG_EPI_AFFINE_LRELU || (epi->ref && epi->bias), BG_ERR_NULL, "conv rows: BG_EPI_AFFINE_LRELU needs ref and bias");
-    p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep; p.alpha = epi->alpha; p.scale = epi->scale;
+    p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep; p.keep_elems = epi->keep_elems; p.alpha = epi->alpha; p.scale = epi->scale;
   }
   const dim3 grid((unsigned)(B * p.strips));
   const double flops = 2.0 * B * (double)Ho * Wo * Cin * Cout * k * k;
@@ -403,7 +405,7 @@ int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B,
     BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "conv rows: epilogue mode %d", epi->mode);
     BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || epi->ref, BG_ERR_NULL, "conv rows: BG_EPI_MUL_GRAD needs ref");
     BG_REQUIRE(epi->mode != BG_EPI_AFFINE_LRELU || (epi->ref && epi->bias), BG_ERR_NULL, "conv rows: BG_EPI_AFFINE_LRELU needs ref and bias");
-    p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep; p.alpha = epi->alpha; p.scale = epi->scale;
+    p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep; p.keep_elems = epi->keep_elems; p.alpha = epi->alpha; p.scale = epi->scale;
   }
   const dim3 grid((unsigned)(cdiv(B, p.ipw) * p.strips));
   const size_t lds = ((size_t)2 * 64 * (p.Ck + 4) + (size_t)2 * s * 64 * 17) * sizeof(float);

@@ -38,8 +38,11 @@ class Stage:
 class Context:
     """Activation / gradient buffers of one pass at a fixed batch size (caller-owned HBM)."""
 
-    def __init__(self, net, B, device):
+    def __init__(self, net, B, device, drop_rows=None):
         self.B = B
+        # Dropout applies to the first ``drop_rows`` samples of the batch only (default: all).  The critic step runs
+        # [fakes; reals] (training=True) and x-hat (training=False) through ONE pass: 2B rows with masks, B without.
+        self.drop_rows = B if drop_rows is None else int(drop_rows)
         f = lambda *s: torch.empty(*s, dtype=torch.float32, device=device)
         self.a0 = f(B, *net.in_shape)
         self.din = None
@@ -55,7 +58,8 @@ class Context:
             self.inv.append(f(c) if st.bn is not None else None)
             self.keep.append(None)
         # dropout masks of all stages live in ONE uint8 buffer (16-byte aligned slices): a pass draws them with one launch
-        sizes = [int(np.prod((B,) + st.out_shape)) if st.drop else 0 for st in net.stages]
+        DR = self.drop_rows
+        sizes = [int(np.prod((DR,) + st.out_shape)) if st.drop else 0 for st in net.stages]
         offs, total = [], 0
         for n in sizes:
             offs.append(total)
@@ -64,12 +68,20 @@ class Context:
         self.keep_total = total
         for i, (st, n) in enumerate(zip(net.stages, sizes)):
             if n:
-                self.keep[i] = self.keep_flat[offs[i]:offs[i] + n].view((B,) + st.out_shape)
+                self.keep[i] = self.keep_flat[offs[i]:offs[i] + n].view((DR,) + st.out_shape)
         rates = {float(st.drop) for st in net.stages if st.drop}
         self.keep_rate = rates.pop() if len(rates) == 1 else None      # None: stages differ, draw per stage
         self._net, self._device = net, device
         self._extra = {}
         self.dropout_active = False
+
+    def keep_elems(self, i):
+        """Output elements of stage i covered by its dropout mask (0 = all of them): the bg_epilogue.keep_elems field."""
+        return 0 if self.drop_rows >= self.B else self.drop_rows * int(np.prod(self._net.stages[i].out_shape))
+
+    def rows(self, lo, hi):
+        """A view of this pass restricted to samples [lo, hi): what gp_second_order needs of the x-hat rows of a merged pass."""
+        return _RowView(self, lo, hi)
 
     def buf(self, lst, i):
         if lst[i] is None:
@@ -86,6 +98,23 @@ class Context:
         if self.din is None:
             self.din = torch.empty((self.B,) + self._net.in_shape, dtype=torch.float32, device=self._device)
         return self.din
+
+
+class _RowView:
+    """Samples [lo, hi) of a Context: sliced activations / gradients, own scratch for the linearised forward."""
+
+    def __init__(self, ctx, lo, hi):
+        self._ctx, self.lo, self.hi, self.B = ctx, lo, hi, hi - lo
+        self.a = [t[lo:hi] for t in ctx.a]
+        self.dz = [None if t is None else t[lo:hi] for t in ctx.dz]
+        key = ("rowview_v", lo, hi)
+        self.v = ctx._extra.setdefault(key, [None] * len(ctx.a))
+        self._net, self._device = ctx._net, ctx._device
+
+    def buf(self, lst, i):
+        if lst[i] is None:
+            lst[i] = torch.empty((self.B,) + self._net.stages[i].out_shape, dtype=torch.float32, device=self._device)
+        return lst[i]
 
 
 class Net:
@@ -136,10 +165,10 @@ class Net:
         self.sync_bn = True       # data parallel: BatchNormalization statistics over the global batch
 
     # ------------------------------------------------------------------ resources
-    def context(self, B, tag="default") -> Context:
-        key = (B, tag)
+    def context(self, B, tag="default", drop_rows=None) -> Context:
+        key = (B, tag, drop_rows)
         if key not in self._ctx:
-            self._ctx[key] = Context(self, B, self.device)
+            self._ctx[key] = Context(self, B, self.device, drop_rows=drop_rows)
         return self._ctx[key]
 
     def workspace(self, nbytes):
@@ -273,7 +302,8 @@ class Net:
                     epi = self._epi(*geom, EPI_NONE, bias=bias)
                 elif st.act == "lrelu":
                     epi = self._epi(*geom, EPI_BIAS_LRELU, bias=bias, keep=keep, alpha=st.alpha,
-                                    scale=1.0 / (1.0 - st.drop) if st.drop else 1.0)
+                                    scale=1.0 / (1.0 - st.drop) if st.drop else 1.0,
+                                    keep_elems=ctx.keep_elems(i) if keep is not None else 0)
                 elif st.act == "tanh":
                     epi = self._epi(*geom, EPI_TANH, bias=bias)
                 else:
@@ -313,15 +343,20 @@ class Net:
         return self.forward(ctx, x, training=training, seed=np.random.randint(1 << 30)).clone()
 
     # ------------------------------------------------------------------ backward
-    def backward(self, ctx: Context, dout, need_dx=False, need_dw=True, beta=0.0, scale=1.0, reducer=None):
+    def backward(self, ctx: Context, dout, need_dx=False, need_dw=True, beta=0.0, scale=1.0, reducer=None, dw_rows=None,
+                 dx_rows=None):
         """Reverse pass of the last ``forward`` on ``ctx``.  Weight gradients go to ``store.grad``
         (= beta*old + scale*new).  Returns d(loss)/d(net input) *before* the blur (or None).
         ``reducer`` (dist.GradReducer): this pass completes the gradients, so each stage's slice of the flat buffer is
-        handed to the bucketed all-reduce as soon as its kernels are enqueued."""
+        handed to the bucketed all-reduce as soon as its kernels are enqueued.
+        ``dw_rows``: weight gradients from the first dw_rows samples only; ``dx_rows`` = (lo, hi): the input gradient (last
+        data-gradient + blur^T) for those samples only -- the merged critic pass wants weights from [fakes; reals] and the
+        image gradient of x-hat."""
         st_ = self.store
         if need_dw:
             st_.ensure_opt_state()
         B = ctx.B
+        WB = B if dw_rows is None else int(dw_rows)
         g, g_is_dz = dout, False
         for i in range(len(self.stages) - 1, -1, -1):
             st = self.stages[i]
@@ -354,8 +389,15 @@ class Net:
                     dz = gv
                 else:
                     keep = ctx.keep[i] if (st.drop and ctx.dropout_active) else None
-                    dz = ops.mul_grad(gv, ctx.a[i], ctx.buf(ctx.dz, i), keep=keep, alpha=st.alpha,
-                                      scale=1.0 / (1.0 - st.drop) if (st.drop and ctx.dropout_active) else 1.0)
+                    dzb = ctx.buf(ctx.dz, i)
+                    if keep is not None and ctx.drop_rows < B:      # masked rows first, the unmasked tail separately
+                        DR = ctx.drop_rows
+                        ops.mul_grad(gv[:DR], ctx.a[i][:DR], dzb[:DR], keep=keep, alpha=st.alpha, scale=1.0 / (1.0 - st.drop))
+                        ops.mul_grad(gv[DR:], ctx.a[i][DR:], dzb[DR:], keep=None, alpha=st.alpha, scale=1.0)
+                        dz = dzb
+                    else:
+                        dz = ops.mul_grad(gv, ctx.a[i], dzb, keep=keep, alpha=st.alpha,
+                                          scale=1.0 / (1.0 - st.drop) if (st.drop and ctx.dropout_active) else 1.0)
             elif st.act == "tanh":
                 dz = ops.tanh_bwd(gv, ctx.a[i], ctx.buf(ctx.dz, i))
             else:
@@ -366,24 +408,25 @@ class Net:
             # ---- weight gradients
             if need_dw:
                 dW = st_.grad_of(lin, "kernel")
+                xw, dzw = (xin, dz) if WB == B else (xin[:WB], dz.view(B, *st.out_shape)[:WB])
                 if st.kind == "dense":
                     K, N = st.in_shape[0], st.out_shape[0]
-                    ops.gemm(xin, dz, dW, K, N, B, transA=True, beta=beta, scale=scale)
-                    rows = B
+                    ops.gemm(xw, dzw, dW, K, N, WB, transA=True, beta=beta, scale=scale)
+                    rows = WB
                 elif st.kind == "conv":
-                    Bc, H, W, Ci = xin.shape
+                    Bc, H, W, Ci = xw.shape
                     nb = ops.conv2d_bwd_filter_workspace_bytes(Bc, H, W, Ci, lin.filters, lin.k, lin.stride)
-                    ops.conv2d_bwd_filter(xin, dz, dW, lin.k, lin.stride, beta, scale, self.workspace(nb) if nb else None)
-                    rows = dz.numel() // lin.filters
+                    ops.conv2d_bwd_filter(xw, dzw, dW, lin.k, lin.stride, beta, scale, self.workspace(nb) if nb else None)
+                    rows = dzw.numel() // lin.filters
                 else:
-                    Bc, H, W, Ci = dz.shape           # conv input side == ConvT output
-                    nb = ops.conv2d_bwd_filter_workspace_bytes(Bc, H, W, Ci, xin.shape[3], lin.k, lin.stride)
-                    ops.conv2d_bwd_filter(dz, xin, dW, lin.k, lin.stride, beta, scale, self.workspace(nb) if nb else None)
-                    rows = dz.numel() // lin.filters
+                    Bc, H, W, Ci = dzw.shape          # conv input side == ConvT output
+                    nb = ops.conv2d_bwd_filter_workspace_bytes(Bc, H, W, Ci, xw.shape[3], lin.k, lin.stride)
+                    ops.conv2d_bwd_filter(dzw, xw, dW, lin.k, lin.stride, beta, scale, self.workspace(nb) if nb else None)
+                    rows = dzw.numel() // lin.filters
                 if "bias" in lin.vars:
                     N = st.out_shape[-1]
                     ws = self.workspace(ops.colsum_workspace_bytes(rows, N))
-                    ops.colsum(dz, st_.grad_of(lin, "bias"), rows, N, ws, beta=beta, scale=scale)
+                    ops.colsum(dzw, st_.grad_of(lin, "bias"), rows, N, ws, beta=beta, scale=scale)
                 if reducer is not None:
                     reducer.ready(*st_.train_range(lin, st.bn))
             # ---- input gradient
@@ -392,21 +435,28 @@ class Net:
             prev = self.stages[i - 1] if i > 0 else None
             fuse = prev is not None and prev.fusable_grad and st.kind != "dense"
             tgt = ctx.buf(ctx.dz, i - 1).view(B, *st.in_shape) if i > 0 else ctx.input_grad().view(B, *st.in_shape)
+            Bx = B
+            if i == 0 and dx_rows is not None:        # the image gradient is wanted for samples [lo, hi) only
+                lo, hi = dx_rows
+                dz = dz.view(B, *st.out_shape)[lo:hi]
+                tgt = tgt[lo:hi]
+                Bx = hi - lo
             epi = None
             if st.kind != "dense":
                 if st.kind == "conv":
-                    geom = (True, B, st.in_shape[0], st.in_shape[1], st.in_shape[2], lin.filters, lin.k, lin.stride)
+                    geom = (True, Bx, st.in_shape[0], st.in_shape[1], st.in_shape[2], lin.filters, lin.k, lin.stride)
                 else:
-                    geom = (False, B, st.out_shape[0], st.out_shape[1], lin.filters, st.in_shape[2], lin.k, lin.stride)
+                    geom = (False, Bx, st.out_shape[0], st.out_shape[1], lin.filters, st.in_shape[2], lin.k, lin.stride)
                 if fuse:
                     pk = ctx.keep[i - 1] if (prev.drop and ctx.dropout_active) else None
                     epi = self._epi(*geom, EPI_MUL_GRAD, ref=ctx.a[i - 1], keep=pk, alpha=prev.alpha,
-                                    scale=1.0 / (1.0 - prev.drop) if pk is not None else 1.0)
+                                    scale=1.0 / (1.0 - prev.drop) if pk is not None else 1.0,
+                                    keep_elems=ctx.keep_elems(i - 1) if pk is not None else 0)
                 else:
                     epi = self._epi(*geom, EPI_NONE)
             if st.kind == "dense":
                 K, N = st.in_shape[0], st.out_shape[0]
-                ops.gemm(dz, lin.vars["kernel"], tgt, B, K, N, transB=True)
+                ops.gemm(dz, lin.vars["kernel"], tgt, Bx, K, N, transB=True)
             elif st.kind == "conv":
                 ops.conv2d_bwd_data(dz, lin.vars["kernel"], tgt, lin.k, lin.stride, epi)
             else:
@@ -414,8 +464,9 @@ class Net:
             g, g_is_dz = tgt, fuse
         din = g
         if self.blur is not None:
-            out = ctx.a0   # forward's blurred input is dead by now; reuse it for blur^T(din)
-            return self.apply_blur(din.view(B, *self.in_shape), out)
+            # forward's blurred input is dead by now; reuse it for blur^T(din)
+            out = ctx.a0 if dx_rows is None else ctx.a0[dx_rows[0]:dx_rows[1]]
+            return self.apply_blur(din.view(din.shape[0], *self.in_shape), out)
         return din
 
     # ------------------------------------------------------------------ GP second order

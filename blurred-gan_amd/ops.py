@@ -56,8 +56,9 @@ def conv2d_splitk_workspace_bytes(bwd_data, B, H, W, Cin, Cout, ksize, stride):
     return _lib.load().bg_conv2d_splitk_workspace_bytes(int(bwd_data), B, H, W, Cin, Cout, ksize, stride)
 
 
-def epilogue(mode=EPI_NONE, bias=None, ref=None, keep=None, alpha=LRELU_ALPHA, scale=1.0, ws=None):
+def epilogue(mode=EPI_NONE, bias=None, ref=None, keep=None, alpha=LRELU_ALPHA, scale=1.0, ws=None, keep_elems=0):
     e = Epilogue()
+    e.keep_elems = int(keep_elems)
     e.splitk_ws = ws.data_ptr() if ws is not None else None
     e.splitk_ws_bytes = ws.numel() * ws.element_size() if ws is not None else 0
     e.mode = mode

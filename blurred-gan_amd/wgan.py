@@ -103,7 +103,7 @@ class WGAN:
 
     def __init__(self, generator: Sequential, discriminator: Sequential, hyperparams: "WGAN.HyperParameters",
                  config: TrainingConfig, *args, reproduce_vector_loss_quirk: bool = True, sync_metrics: bool = True,
-                 sync_batchnorm: bool = True, **kwargs):
+                 sync_batchnorm: bool = True, merge_critic_passes: bool = True, **kwargs):
         self.hparams = hyperparams
         if str(self.hparams.optimizer).lower() != "adam":
             raise NotImplementedError("only the reference's default optimizer 'adam' is implemented (wgan.py:43,56)")
@@ -130,6 +130,8 @@ class WGAN:
         self.reproduce_vector_loss_quirk = reproduce_vector_loss_quirk
         self.sync_metrics = sync_metrics     # False: skip the per-step device->host metric read (bench)
         self.sync_batchnorm = sync_batchnorm  # DP: generator BN statistics over the global batch (False = per replica)
+        # critic step: [fakes; reals] and x-hat in one 3B-sample forward / backward (False: two passes, as the reference orders them)
+        self.merge_critic_passes = merge_critic_passes and not os.environ.get("BGAN_NO_MERGED_CRITIC")
         self._rng_seed = get_seed()
         self._rng_off = 0
         self._bufs = {}
@@ -231,34 +233,61 @@ class WGAN:
         z = self._inj("z_d")
         z = self._as_device(z) if z is not None else self._uniform("z_d", (B, self.latent_size))
         fakes = G.forward(G.context(B, "g_dstep"), z, training=False)           # Q4: inference BN in the D-step
-        cfr = D.context(2 * B, "fr")
         masks = None
         if self._inj("mask_fake") is not None:
             masks = [torch.cat([self._as_mask(a), self._as_mask(b)], 0)
                      for a, b in zip(self._inj("mask_fake"), self._inj("mask_real"))]
-        s2 = D.forward(cfr, [fakes, reals], training=True, masks=masks, seed=self._rng_seed + 104729 * (dist.rank() + 1)).view(2 * B)
-        fs, rs = s2[:B], s2[B:]
         inv_gbs = 1.0 / float(hp.global_batch_size)
-        norms = g = None
-        if self.uses_gradient_penalty:
-            norms, g = self._gp_first_order(reals, fakes)
-        ds2 = self._buf("ds2", (2 * B,))
+        gp_c = float(getattr(hp, "gp_coefficient", 0.0)) if self.uses_gradient_penalty else 0.0
+        e_d = float(getattr(hp, "e_drift", 0.0)) if self.uses_gradient_penalty else 0.0
         met = self._buf("d_metrics", (8,))
         vs = self._vec_scale(B)
-        ops.wgangp_d_loss(fs, rs, norms, inv_gbs, float(getattr(hp, "gp_coefficient", 0.0)) if self.uses_gradient_penalty else 0.0,
-                          float(getattr(hp, "e_drift", 0.0)) if self.uses_gradient_penalty else 0.0, vs, ds2[:B], ds2[B:], met)
         store = self.discriminator.store
         store.ensure_opt_state()
         red = dist.GradReducer(store.grad, store.n_train)       # buckets go out while the backward is still running
-        D.backward(cfr, ds2.view(2 * B, 1), need_dx=False, need_dw=True, beta=0.0, scale=1.0,
-                   reducer=None if self.uses_gradient_penalty else red)
-        if self.uses_gradient_penalty:
-            # d/dW of vec_scale * gp_coefficient * mean_global((n-1)^2): seed carries the whole factor
+        seed = self._rng_seed + 104729 * (dist.rank() + 1)
+        merged = (self.uses_gradient_penalty and self.merge_critic_passes and all(st.bn is None for st in D.stages))
+        if merged:
+            # [fakes; reals] (training=True: Dropout) and x-hat (training=False) share every weight: ONE 3B-sample pass forward
+            # and ONE backward, the Dropout masks covering the first 2B samples only (bg_epilogue.keep_elems).  The seeds of
+            # the backward do not depend on the penalty (d loss / d scores is +-1/gbs and the drift term), so the x-hat rows
+            # ride along with seed 1 and come out as the zeta_i the second-order pass needs; weight gradients use rows [0, 2B),
+            # the image gradient is taken for rows [2B, 3B) only.
+            a = self._inj("alpha")
+            a = self._as_device(a).view(B) if a is not None else self._uniform("alpha", (B,))
+            xhat = ops.lerp(reals, fakes, a, self._buf("xhat", tuple(reals.shape)))
+            c3 = D.context(3 * B, "fr3", drop_rows=2 * B)
+            s3 = D.forward(c3, [fakes, reals, xhat], training=True, masks=masks, seed=seed).view(3 * B)
+            fs, rs = s3[:B], s3[B:2 * B]
+            ds3 = self._buf("ds3", (3 * B,))
+            ops.fill(ds3[2 * B:], 1.0)
+            ops.wgangp_d_loss(fs, rs, None, inv_gbs, gp_c, e_d, vs, ds3[:B], ds3[B:2 * B], met)      # seeds only; metrics below
+            g = D.backward(c3, ds3.view(3 * B, 1), need_dx=True, need_dw=True, beta=0.0, scale=1.0, dw_rows=2 * B,
+                           dx_rows=(2 * B, 3 * B))
+            norms = ops.row_norm(g, self._buf("gp_norms", (B,)))
+            ops.wgangp_d_loss(fs, rs, norms, inv_gbs, gp_c, e_d, vs, ds3[:B], ds3[B:2 * B], met)    # same seeds, full metrics
             coef = vs * float(hp.gp_coefficient) * 2.0 / float(B * dist.world_size())
             gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)))
-            chat = D.context(B, "hat")
             v0 = D.apply_blur(gbar, self._buf("v0", tuple(g.shape))) if D.blur is not None else gbar
-            D.gp_second_order(chat, v0, reducer=red)
+            D.gp_second_order(c3.rows(2 * B, 3 * B), v0, reducer=red)
+        else:
+            cfr = D.context(2 * B, "fr")
+            s2 = D.forward(cfr, [fakes, reals], training=True, masks=masks, seed=seed).view(2 * B)
+            fs, rs = s2[:B], s2[B:]
+            norms = g = None
+            if self.uses_gradient_penalty:
+                norms, g = self._gp_first_order(reals, fakes)
+            ds2 = self._buf("ds2", (2 * B,))
+            ops.wgangp_d_loss(fs, rs, norms, inv_gbs, gp_c, e_d, vs, ds2[:B], ds2[B:], met)
+            D.backward(cfr, ds2.view(2 * B, 1), need_dx=False, need_dw=True, beta=0.0, scale=1.0,
+                       reducer=None if self.uses_gradient_penalty else red)
+            if self.uses_gradient_penalty:
+                # d/dW of vec_scale * gp_coefficient * mean_global((n-1)^2): seed carries the whole factor
+                coef = vs * float(hp.gp_coefficient) * 2.0 / float(B * dist.world_size())
+                gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)))
+                chat = D.context(B, "hat")
+                v0 = D.apply_blur(gbar, self._buf("v0", tuple(g.shape))) if D.blur is not None else gbar
+                D.gp_second_order(chat, v0, reducer=red)
         red.finish()
         self.discriminator.optimizer.apply(store)
         self._d_metrics_dev = met

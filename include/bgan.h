@@ -94,6 +94,9 @@ typedef struct {
   float scale;            /* 1 / keep_prob                                                      */
   void* splitk_ws;        /* optional scratch for split-K partial sums (small-M layers); NULL = never split */
   size_t splitk_ws_bytes; /* >= bg_conv2d_splitk_workspace_bytes(...) for the call to use split-K      */
+  size_t keep_elems;      /* the keep mask covers output elements [0, keep_elems) only (a batch whose leading samples ran with
+                           * Dropout and whose trailing samples without: fake+real and x-hat of wgan.py:138,240 in one pass);
+                           * 0 = every element */
 } bg_epilogue;
 
 /* bytes of split-K scratch the forward (bwd_data = 0) / data-gradient (bwd_data = 1) call can use; 0 = never splits */
