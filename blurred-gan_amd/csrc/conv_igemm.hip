@@ -726,7 +726,7 @@ int plan_splitk(const GatherParams& p, int bm, int bn, int bk) {
   // shorter workgroups balance better than one round of long ones (G2: 0.225 -> 0.205 ms data gradient, 0.202 -> 0.189 forward)
   int maxpos = 0;
   for (int i = 0; i < p.nphase; ++i) maxpos = std::max(maxpos, p.ph[i].Ha * p.ph[i].Wa);
-  const bool skipping = maxpos <= 64 && p.B >= bm && p.B % bm == 0;
+  const bool skipping = maxpos <= 16 && p.B >= bm && p.B % bm == 0;      // 8x8 maps lose a quarter of their taps at most: not worth it (G3: 0.22 -> 0.26 ms)
   if (skipping && wgs >= min_wgs && wgs <= 2 * min_wgs && min_steps >= 64) {
     const int ks = (int)std::min<long>(4, 4L * min_wgs / wgs);
     return std::max(1, std::min(ks, min_steps / 32));
