@@ -1170,8 +1170,10 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
   // more, shorter workgroups balance better than the round model predicts (measured: G1 0.33 ms at 800 workgroups, 0.40 at 400)
   const bool skipping = Ho * Wo <= 16 && B >= 128 && (B & (B - 1)) == 0;
   if (old_plan || pl.taps_in_grid != 1 || skipping) {     // tap-grouped kernel: measured slower with the model's single full round (0.35 vs 0.28 ms)
-    static const int tgt = getenv("BG_WGRAD_TARGET") ? atoi(getenv("BG_WGRAD_TARGET")) : 768;   // tuning aid
-    want = std::max(1L, (tgt + base - 1) / base);                 // aim for ~3 workgroups per CU
+    static const int tgt_env = getenv("BG_WGRAD_TARGET") ? atoi(getenv("BG_WGRAD_TARGET")) : 0;   // tuning aid
+    // ~3 workgroups per CU; the tap-grouped kernel (3 resident per CU) measured best at two full rounds (G5: 0.30 -> 0.27 ms)
+    const int tgt = tgt_env ? tgt_env : (pl.taps_in_grid == 2 && M >= 200000 ? 1536 : 768);
+    want = std::max(1L, (tgt + base - 1) / base);
     want = std::min(want, std::max(1L, steps / 4));               // at least 4 K-steps per workgroup
     if ((size_t)kk * Ci * Co * sizeof(float) > (8u << 20)) want = std::min(want, 2L);   // big slabs: the reduce pass costs more than idle CUs
   } else {
