@@ -51,8 +51,6 @@ __global__ __launch_bounds__(256) void conv_rows_scatter_kernel(const RowParams 
   const int li = lane & 15, kq = lane >> 4;
   const int t = wave % p.wpr, img = wave / p.wpr;
   const int strip = blockIdx.x % p.strips, bgrp = blockIdx.x / p.strips;
-  const int b = bgrp * p.ipw + img;
-  const bool img_ok = b < p.B;
   const int Ck = 4 * KS, N = p.N;
   const int y0 = strip * p.R, y1 = min(y0 + p.R, p.Ho);
   const int iy_lo = -floordiv(-(y0 + p.pt - (K - 1)), S);          // ceil((y0 + pt - (K-1)) / S)
