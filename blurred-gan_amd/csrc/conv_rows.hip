@@ -41,12 +41,13 @@ struct RowParams {
 
 __device__ inline int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
-template <int KS, int K, int S>     // Ck = 4*KS, K x K taps, stride S of the scatter
-__global__ __launch_bounds__(256) void conv_rows_scatter_kernel(const RowParams p) {
+template <int KS, int K, int S, int PIXW>     // Ck = 4*KS, K x K taps, stride S of the scatter, PIXW input pixels per workgroup
+__global__ __launch_bounds__(PIXW * 4) void conv_rows_scatter_kernel(const RowParams p) {
+  constexpr int NTH = PIXW * 4;                              // one wave per 16 input pixels
   extern __shared__ __attribute__((aligned(16))) float row_lds[];
   constexpr int AS = 4 * KS + 4;                             // A row stride in LDS: conflict-free b32 fragment reads, 16-B aligned rows
   float* abuf = row_lds;                                     // [2][ipw * Wi][AS]   input rows r, r+1
-  float* pbuf = row_lds + 2 * 64 * AS;                       // [2][S][ipw * Wi][17] finished P tiles (ipw * Wi = 64 pixels)
+  float* pbuf = row_lds + 2 * PIXW * AS;                     // [2][S][ipw * Wi][17] finished P tiles (ipw * Wi = PIXW pixels)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int t = wave % p.wpr, img = wave / p.wpr;
@@ -75,13 +76,13 @@ __global__ __launch_bounds__(256) void conv_rows_scatter_kernel(const RowParams 
   // Input rows travel global -> registers (coalesced float4, two rows ahead) -> LDS -> A fragments; a direct gather of the
   // fragment layout from global (16 cache lines per wave instruction) cost as much as all the MFMAs.
   constexpr int QPR = KS;                                    // float4 per pixel
-  constexpr int NQ = 64 * QPR / 256;                         // float4 per thread per row set (64 pixels x Ck)
+  constexpr int NQ = PIXW * QPR / NTH;                       // float4 per thread per row set (PIXW pixels x Ck)
   static_assert(NQ >= 1, "Ck >= 16");
   auto gload = [&](int r, float4 (&g)[NQ]) {
     const int iy = iy_lo + r;
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int f = tid + q * 256, pix = f / QPR, c4 = f - pix * QPR;        // pix = im * Wi + ix
+      const int f = tid + q * NTH, pix = f / QPR, c4 = f - pix * QPR;        // pix = im * Wi + ix
       const int im = pix / p.Wi, ix = pix - im * p.Wi;
       const int bb = bgrp * p.ipw + im;
       const bool ok = bb < p.B && r < nrows && (unsigned)iy < (unsigned)p.Hi;
@@ -91,14 +92,14 @@ __global__ __launch_bounds__(256) void conv_rows_scatter_kernel(const RowParams 
   auto lstore = [&](int buf, const float4 (&g)[NQ]) {
 #pragma unroll
     for (int q = 0; q < NQ; ++q) {
-      const int f = tid + q * 256, pix = f / QPR, c4 = f - pix * QPR;
-      *reinterpret_cast<float4*>(abuf + (size_t)buf * 64 * AS + pix * AS + c4 * 4) = g[q];
+      const int f = tid + q * NTH, pix = f / QPR, c4 = f - pix * QPR;
+      *reinterpret_cast<float4*>(abuf + (size_t)buf * PIXW * AS + pix * AS + c4 * 4) = g[q];
     }
   };
   const float* afrag = abuf + ((size_t)img * p.Wi + 16 * t + li) * AS + kq;
   // Row-independent part of the kw shift-add, per thread: output element e = (image, x, n) of a finished row sums the
   // P columns (kw, n) of the input pixels ix = (x + pl - kw) / S that exist.  Offsets into one P buffer, -1 = no term.
-  constexpr int NE = 3;                                      // output elements per thread: ipw * Wo * N <= 4 * 64 * 3 = 768
+  constexpr int NE = 3;                                      // output elements per thread: ipw * Wo * N <= 3 * NTH (host-checked)
   constexpr int NTERM = (K + S - 1) / S;
   int e_src[NE][NTERM];
   long e_dst[NE];                                            // offset of (image, y = 0, x, n) in the output, -1 = none
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void conv_rows_scatter_kernel(const RowParams 
     const int per_img = p.Wo * N;
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
-      const int e = tid + q * 256;
+      const int e = tid + q * NTH;
       const int im = e / per_img, rem = e - im * per_img;
       const int x = rem / N, n = rem - x * N;
       const int bb = bgrp * p.ipw + im;
@@ -124,12 +125,12 @@ __global__ __launch_bounds__(256) void conv_rows_scatter_kernel(const RowParams 
   }
   // finished output row y: P tile -> LDS (before the row's barrier), then kw shift-add, epilogue, contiguous stores (after it)
   auto pwrite = [&](const floatx4& pacc, int slot) {
-    float* pb = pbuf + (size_t)slot * 64 * 17;
+    float* pb = pbuf + (size_t)slot * PIXW * 17;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) pb[((size_t)img * p.Wi + 16 * t + 4 * kq + rr) * 17 + li] = pacc[rr];
   };
   auto pstore = [&](int slot, int y) {
-    const float* pb = pbuf + (size_t)slot * 64 * 17;
+    const float* pb = pbuf + (size_t)slot * PIXW * 17;
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
       if (e_dst[q] < 0) continue;
@@ -155,7 +156,7 @@ __global__ __launch_bounds__(256) void conv_rows_scatter_kernel(const RowParams 
     const int iy = iy_lo + r, cur = r & 1;
     float a[KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) a[ks] = afrag[(size_t)cur * 64 * AS + 4 * ks];
+    for (int ks = 0; ks < KS; ++ks) a[ks] = afrag[(size_t)cur * PIXW * AS + 4 * ks];
     // registers alternate by row parity; the branch is uniform
     if (cur == 0) { lstore(1, g1); gload(r + 2, g0); } else { lstore(0, g0); gload(r + 2, g1); }
 #pragma unroll
@@ -180,12 +181,16 @@ __global__ __launch_bounds__(256) void conv_rows_scatter_kernel(const RowParams 
 
 template <int K, int S>
 int launch_rows(const RowParams& p, dim3 grid, size_t lds, hipStream_t s) {
+  const bool wide = p.Wi == 128;
+#define BG_RS(KSv) do { if (wide) hipLaunchKernelGGL((conv_rows_scatter_kernel<KSv, K, S, 128>), grid, dim3(512), lds, s, p); \
+                        else hipLaunchKernelGGL((conv_rows_scatter_kernel<KSv, K, S, 64>), grid, dim3(256), lds, s, p); } while (0)
   switch (p.Ck) {
-    case 16: hipLaunchKernelGGL((conv_rows_scatter_kernel<4, K, S>), grid, dim3(256), lds, s, p); return 1;
-    case 32: hipLaunchKernelGGL((conv_rows_scatter_kernel<8, K, S>), grid, dim3(256), lds, s, p); return 1;
-    case 64: hipLaunchKernelGGL((conv_rows_scatter_kernel<16, K, S>), grid, dim3(256), lds, s, p); return 1;
+    case 16: BG_RS(4); return 1;
+    case 32: BG_RS(8); return 1;
+    case 64: BG_RS(16); return 1;
     default: return 0;
   }
+#undef BG_RS
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -390,14 +395,16 @@ int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B,
     if (s != 1 || Cout * k > 16 || (Cin != 16 && Cin != 32 && Cin != 64)) return BG_OK;
     p.Hi = H; p.Wi = W; p.Ck = Cin; p.Ho = H; p.Wo = W; p.N = Cout; p.pt = k - 1 - pt; p.pl = k - 1 - pl; p.flip = 1;
   }
-  if (p.Wi != 16 && p.Wi != 32 && p.Wi != 64) return BG_OK;                           // a workgroup handles 64 pixels: 4 / 2 / 1 images
+  if (p.Wi != 16 && p.Wi != 32 && p.Wi != 64 && p.Wi != 128) return BG_OK;            // a workgroup handles 64 pixels (4 / 2 / 1 images) or one 128-pixel row
   if ((size_t)B * p.Hi * p.Wi * p.Ck >= (1ull << 31) || (size_t)B * p.Ho * p.Wo * p.N >= (1ull << 31)) return BG_OK;
   p.A = a; p.Wt = w; p.C = c; p.B = B;
   static const int rows_r = getenv("BG_ROWS_R") ? atoi(getenv("BG_ROWS_R")) : 0;       // tuning aid
   p.R = std::min(rows_r ? rows_r : (s == 1 ? 32 : 16), p.Ho);                        // measured: halo rows (k-1)/s per strip vs workgroups in flight
   p.strips = (int)cdiv(p.Ho, p.R);
   p.wpr = p.Wi / 16;
-  p.ipw = 4 / p.wpr;
+  p.ipw = p.Wi == 128 ? 1 : 4 / p.wpr;
+  const int pixw = p.Wi == 128 ? 128 : 64;
+  if ((long)p.ipw * p.Wo * p.N > 3L * pixw * 4) return BG_OK;                          // output elements per thread of the shift-add
   p.epi_mode = BG_EPI_NONE; p.alpha = 0.3f; p.scale = 1.f;
   if (epi) {
     BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "conv rows: epilogue mode %d", epi->mode);
@@ -406,7 +413,7 @@ int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B,
     p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep; p.keep_elems = epi->keep_elems; p.alpha = epi->alpha; p.scale = epi->scale;
   }
   const dim3 grid((unsigned)(cdiv(B, p.ipw) * p.strips));
-  const size_t lds = ((size_t)2 * 64 * (p.Ck + 4) + (size_t)2 * s * 64 * 17) * sizeof(float);
+  const size_t lds = ((size_t)2 * pixw * (p.Ck + 4) + (size_t)2 * s * pixw * 17) * sizeof(float);
   const double flops = 2.0 * B * (double)H * W * Cin * Cout * k * k / (s * s);
   Launch L(stream, bwd_data ? "conv_rows_dgrad" : "conv_rows_fwd", flops, 0);
   int ok;
