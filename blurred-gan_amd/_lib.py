@@ -70,7 +70,13 @@ SIGNATURES = {
     "bg_adam_f32": (_i, [_p, _p, _p, _p, _z, _f, _f, _f, _f, _p]),
     "bg_uniform_f32": (_i, [_p, _z, _u64, _u64, _p]),
     "bg_keep_mask_u8": (_i, [_p, _z, _f, _u64, _u64, _p]),
+    "bg_comm_unique_id": (_i, [C.c_char_p]),
+    "bg_comm_init": (_i, [C.POINTER(_p), _i, _i, C.c_char_p]),
+    "bg_allreduce_sum_f32": (_i, [_p, _p, _z, _p]),
+    "bg_comm_destroy": (_i, [_p]),
 }
+
+COMM_ID_BYTES = 128
 
 _lib = None
 
@@ -99,5 +105,5 @@ def check(status, what=""):
         lib = load()
         msg = lib.bg_last_error().decode("utf-8", "replace")
         kind = lib.bg_status_string(status).decode()
-        exc = ValueError if status in (-1, -2, -3, -6) else BgError
+        exc = ValueError if status in (-1, -2, -3, -6) else BgError     # -4 HIP, -5 workspace, -7 RCCL
         raise exc(f"{what}: {kind}: {msg}")

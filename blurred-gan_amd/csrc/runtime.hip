@@ -60,6 +60,7 @@ const char* bg_status_string(int s) {
     case BG_ERR_HIP: return "HIP runtime error";
     case BG_ERR_WORKSPACE: return "workspace missing or too small";
     case BG_ERR_NULL: return "null pointer";
+    case BG_ERR_RCCL: return "RCCL error";
     default: return "unknown status";
   }
 }

@@ -50,13 +50,74 @@ def init_from_env(backend=None):
 def all_reduce_sum_(flat):
     """In-place SUM all-reduce of a flat gradient buffer (no-op for a single replica)."""
     if world_size() > 1:
-        if flat.is_cuda and td.get_backend() == "gloo":      # CPU test harness: stage through the host
+        if _use_abi_comm(flat):
+            AbiComm.get().all_reduce_async(flat).wait()
+        elif flat.is_cuda and td.get_backend() == "gloo":    # CPU test harness: stage through the host
             host = flat.cpu()
             td.all_reduce(host, op=td.ReduceOp.SUM)
             flat.copy_(host)
         else:
             td.all_reduce(flat, op=td.ReduceOp.SUM)          # RCCL ring/tree over xGMI on the GPU box
     return flat
+
+
+class AbiComm:
+    """The C ABI's own communicator (include/bgan.h: bg_comm_init / bg_allreduce_sum_f32), i.e. RCCL called from
+    libbgan_hip.so instead of through torch.  The unique id travels over the already-initialised torch.distributed group
+    (any backend); collectives run on a private stream ordered after the kernels enqueued so far, like torch's own.
+    Selected with BGAN_DP_COLLECTIVE=abi; one communicator per process."""
+
+    _inst = None
+
+    def __init__(self):
+        import ctypes as C
+        from . import _lib
+        lib = _lib.load()
+        idbuf = C.create_string_buffer(_lib.COMM_ID_BYTES)
+        if rank() == 0:
+            _lib.check(lib.bg_comm_unique_id(idbuf), "bg_comm_unique_id")
+        box = [bytes(idbuf.raw)]
+        if world_size() > 1:
+            td.broadcast_object_list(box, src=0)
+        self._lib, self._check = lib, _lib.check
+        self._h = C.c_void_p()
+        _lib.check(lib.bg_comm_init(C.byref(self._h), rank(), world_size(), box[0]), "bg_comm_init")
+        self.stream = torch.cuda.Stream()
+
+    @classmethod
+    def get(cls):
+        if cls._inst is None:
+            cls._inst = cls()
+        return cls._inst
+
+    def all_reduce_async(self, seg):
+        """Enqueues the in-place SUM of ``seg`` behind the current stream's work; returns an object with .wait()."""
+        ev = torch.cuda.Event()
+        ev.record()
+        self.stream.wait_event(ev)
+        self._check(self._lib.bg_allreduce_sum_f32(self._h, seg.data_ptr(), seg.numel(), self.stream.cuda_stream),
+                    "bg_allreduce_sum_f32")
+        done = torch.cuda.Event()
+        done.record(self.stream)
+        return _AbiWork(done)
+
+    def close(self):
+        if self._h:
+            self._check(self._lib.bg_comm_destroy(self._h), "bg_comm_destroy")
+            self._h = None
+        AbiComm._inst = None
+
+
+class _AbiWork:
+    def __init__(self, ev):
+        self.ev = ev
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.ev)
+
+
+def _use_abi_comm(t):
+    return t.is_cuda and os.environ.get("BGAN_DP_COLLECTIVE", "") == "abi"
 
 
 class GradReducer:
@@ -81,7 +142,9 @@ class GradReducer:
             return
         seg = self.flat[lo:hi]
         self.n_collectives += 1
-        if seg.is_cuda and td.get_backend() == "gloo":          # CPU-side rehearsal: stage through the host, synchronous
+        if _use_abi_comm(seg):
+            self.works.append(AbiComm.get().all_reduce_async(seg))
+        elif seg.is_cuda and td.get_backend() == "gloo":        # CPU-side rehearsal: stage through the host, synchronous
             host = seg.cpu()
             td.all_reduce(host, op=td.ReduceOp.SUM)
             seg.copy_(host)

@@ -36,7 +36,8 @@ typedef enum {
   BG_ERR_UNSUPPORTED = -3,    /* valid request this build has no kernel for                    */
   BG_ERR_HIP = -4,            /* a HIP runtime call failed (message has hipGetErrorString)     */
   BG_ERR_WORKSPACE = -5,      /* workspace missing or too small (see *_workspace_bytes)        */
-  BG_ERR_NULL = -6            /* required pointer is NULL                                      */
+  BG_ERR_NULL = -6,           /* required pointer is NULL                                      */
+  BG_ERR_RCCL = -7            /* RCCL missing or a collective call failed (message has the RCCL string) */
 } bg_status;
 
 /* ---- meta ------------------------------------------------------------------------------- */
@@ -202,6 +203,19 @@ int bg_adam_f32(float* theta, float* m, float* v, const float* g, size_t n, floa
 /* ---- RNG: tf.random.uniform (wgan.py:118,237) and Dropout masks; counter-based, own stream ---- */
 int bg_uniform_f32(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
 int bg_keep_mask_u8(uint8_t* out, size_t n, float keep_prob, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---- data-parallel exchange step (the reference never ran multi-GPU, demo_mnist.py:116) --------
+ * One process per GPU.  Rank 0 makes an id and hands its BG_COMM_ID_BYTES bytes to the other ranks over the host's
+ * own channel (env, file, torch.distributed store ...); every rank then calls bg_comm_init with the HIP device it
+ * trains on current.  bg_allreduce_sum_f32 is the step's only collective: in-place SUM of a flat fp32 gradient range
+ * over RCCL (xGMI inside a node), asynchronous on `stream`.  RCCL is loaded on first use (BGAN_RCCL_LIB overrides
+ * the library name); BG_ERR_RCCL when it is absent or a call fails. */
+#define BG_COMM_ID_BYTES 128
+typedef struct bg_comm bg_comm;
+int bg_comm_unique_id(unsigned char* id_out);
+int bg_comm_init(bg_comm** out, int rank, int nranks, const unsigned char* id_bytes);
+int bg_allreduce_sum_f32(bg_comm* comm, float* buf_d, size_t n, void* stream);
+int bg_comm_destroy(bg_comm* comm);
 
 #ifdef __cplusplus
 }

@@ -70,6 +70,16 @@ def test_errors_are_statuses_not_crashes(lib):
     assert lib.bg_conv2d_bwd_filter_workspace_bytes(256, 32, 32, 32, 64, 5, 2) > 0
 
 
+def test_comm_argument_errors_are_statuses(lib):
+    h = C.c_void_p()
+    assert lib.bg_comm_init(C.byref(h), 2, 2, b"\0" * 128) == -1          # rank out of range, checked before RCCL is touched
+    assert lib.bg_comm_init(None, 0, 1, b"\0" * 128) == -6
+    assert lib.bg_comm_unique_id(None) == -6
+    assert lib.bg_allreduce_sum_f32(None, None, 4, None) == -6
+    assert lib.bg_comm_destroy(None) == 0
+    assert lib.bg_status_string(-7) == b"RCCL error"
+
+
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     from blurred_gan_amd import _lib
     monkeypatch.setattr(_lib, "_lib", None)

@@ -86,3 +86,36 @@ def test_two_ranks_match_single_process_global_batch(tmp_path):
     s0, s1 = np.load(tmp_path / "g_state_0.npy"), np.load(tmp_path / "g_state_1.npy")
     np.testing.assert_array_equal(s0, s1)
     np.testing.assert_allclose(s0, sg.state[:sg.n_state].cpu().numpy(), rtol=1e-4, atol=1e-6)      # BN moving statistics
+
+
+def test_abi_communicator_single_rank():
+    """include/bgan.h's own RCCL communicator (bg_comm_*): with one rank the SUM all-reduce is the identity, runs on the
+    stream it is given and leaves the buffer untouched; the handle is created and destroyed without touching torch.distributed.
+    (Two RCCL ranks cannot share the single card of the test box; the N>1 wiring is covered by the gloo tests.)"""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from blurred_gan_amd import dist
+    torch.cuda.set_device(0)
+    comm = dist.AbiComm()
+    x = torch.randn(1 << 20, device="cuda")
+    ref = x.clone()
+    y = x * 2.0                      # enqueue work the collective must be ordered after
+    w = comm.all_reduce_async(y)
+    w.wait()
+    z = y + 1.0
+    torch.cuda.synchronize()
+    assert torch.equal(y, ref * 2.0) and torch.equal(z, ref * 2.0 + 1.0)
+    comm.close()
+
+
+def test_abi_communicator_argument_errors():
+    import ctypes as C
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from blurred_gan_amd import _lib
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.bg_comm_init(C.byref(h), 2, 2, b"\0" * 128) == -1          # rank out of range
+    assert lib.bg_comm_init(None, 0, 1, b"\0" * 128) == -6
+    assert lib.bg_allreduce_sum_f32(None, None, 4, None) == -6
+    assert lib.bg_comm_destroy(None) == 0
