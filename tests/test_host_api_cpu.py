@@ -2,6 +2,7 @@
 own asserts, parameter counts, hyper-parameter dataclasses / CLI / JSON, callbacks' sigma schedule, fit protocol."""
 import argparse
 import json
+import os
 
 import numpy as np
 import pytest
@@ -156,3 +157,45 @@ def test_feed_images_to_metric_callback_counts():
     for b in range(8):
         cb.on_batch_end(b, {"size": 32})
     assert cb.results == [50.0, 50.0]        # recorded exactly num_samples each time (32 + 18), reference callbacks.py:156-173
+
+
+def test_utils_file_and_image_helpers(tmp_path):
+    """reference utils.py:27-103: run/epoch parsing, newest model file of the latest run, layout helpers, sample grid."""
+    import dataclasses
+    import numpy as np
+    import torch
+    from blurred_gan_amd import utils
+    assert utils.run_id("results/07-mnist/model_12.hdf5") == 7
+    assert utils.epoch("results/07-mnist/model_12.hdf5") == 12
+    for run, eps in (("01-mnist", (1, 30)), ("03-mnist", (2, 11, 9)), ("02-celeba", (50,))):
+        os.makedirs(tmp_path / run)
+        for e in eps:
+            (tmp_path / run / f"model_{e}.hdf5").write_text("")
+    assert utils.locate_model_file(str(tmp_path), "mnist").endswith("03-mnist/model_11.hdf5")
+    assert utils.locate_model_file(str(tmp_path), "celeba").endswith("02-celeba/model_50.hdf5")
+    with pytest.raises(FileNotFoundError):
+        utils.locate_model_file(str(tmp_path), "lsun")
+    x = torch.arange(2 * 3 * 4 * 5).reshape(2, 3, 4, 5)
+    assert utils.NHWC_to_NCHW(x).shape == (2, 5, 3, 4)
+    assert torch.equal(utils.NCHW_to_NHWC(utils.NHWC_to_NCHW(x)), x)
+    assert np.array_equal(utils.NCHW_to_NHWC(utils.NHWC_to_NCHW(x.numpy())), x.numpy())
+    s = np.random.default_rng(0).uniform(size=(70, 4, 6, 3)).astype(np.float32)
+    g = utils.samples_grid(s)
+    assert g.shape == (32, 48, 3)
+    assert np.array_equal(g[4:8, 12:18], s[1 * 8 + 2])            # row 1, column 2 of the grid is sample 10
+    assert utils.samples_grid(s[..., :1]).shape == (32, 48)
+    img = utils.plot_to_image(g)
+    assert img.shape == (1, 32, 48, 4) and img.dtype == np.uint8 and (img[..., 3] == 255).all()
+    ds = utils.to_dataset(s)
+    assert len(ds) == 70 and np.array_equal(next(iter(ds)), s[0])
+    it = iter([1, 2])
+    assert utils.to_dataset(it) is it
+
+    @dataclasses.dataclass
+    class HP(utils.HyperParams):
+        lr: float = 1e-3
+        n: int = 5
+    hp = HP(n=7)
+    assert str(hp) == str({"lr": 1e-3, "n": 7})
+    hp.save_json(str(tmp_path / "hp.json"))
+    assert HP.from_json(str(tmp_path / "hp.json")) == hp
