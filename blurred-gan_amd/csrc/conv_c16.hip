@@ -1,0 +1,212 @@
+// Row-staged MFMA kernels for the 16-channel ends of the 128x128 networks (reference demo_celeba.py:84-90 ConvT 32->16,
+// :99-103 Conv 16->32 and their gradients, wgan.py:140,166,244).  SURVEY.md 8a rows T1/T2, config C4.
+//
+// With 16 channels on one side a gather-GEMM tile is half padding (the 32-wide MFMA needs N >= 32) and, worse, re-reads every
+// source pixel once per tap from L2: 25 taps x 128 B per 64 B of output made the per-tap gather the bound (measured 37 TFLOP/s
+// on ConvT 32->16 at 128x128).  These kernels stage the source ROWS in LDS once (register-prefetched, double-buffered, zero
+// halo columns), keep the whole 5x5 weight set in LDS, and run v_mfma_f32_16x16x4_f32 tiles whose N is exactly 16:
+//   conv_c16_dgrad_kernel   data gradient of a stride-2 5x5 conv with Cin = 16 (== forward of ConvT -> 16 channels):
+//                           out[b, 2a+py, 2c+px, n] = sum_{kh = py+1 (2), kw = px+1 (2), ck} src[b, a + (py+1-kh)/2, c + (px+1-kw)/2, ck] * w[kh,kw][n][ck]
+// Workgroups are persistent (the weights are loaded once) and loop over strips of 2 anchor rows (4 output rows).
+#include "conv_common.h"
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+namespace {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr unsigned kOob = 0x80000000u;
+
+struct C16Params {
+  const float* A;    // source rows [B][Hs][Ws][Ck]
+  const float* Wt;   // [25][16][Ck]
+  float* C;          // [B][Hd][Wd][16]
+  int B, Hs, Ws, Ck, Hd, Wd, N;
+  int nstrips, strips_per_img;
+  unsigned a_bytes, w_bytes;
+  int epi_mode;
+  const float* bias;
+  const float* ref;
+  const unsigned char* keep;
+  size_t keep_elems;
+  float alpha, scale;
+};
+
+// ------------------------------------------------------------------------------------------------------------------------
+// data gradient, N = 16, Ck = 32, k = 5, s = 2, even H and W (pt = pl = 1): phase (py, px) of output pixel (2a+py, 2c+px) takes
+// kernel rows kh = py+1 (mod 2) from source row a + (py+1-kh)/2 in {a-1, a, a+1}, same along the row.
+// LDS: weights [25*16][36], rows [2 buffers][4 rows: a0-1 .. a0+2][(WS + 2) pixels][36]; pixel stride 36 floats keeps the b128
+// fragment reads of 16 lanes on distinct banks.  Wave w: anchor row a0 + (w >> 1), anchor columns (w & 1) * WS/2 ...
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kDgCk = 32, kDgAst = kDgCk + 4, kDgRows = 4;
+
+template <int WS>
+__global__ __launch_bounds__(256) void conv_c16_dgrad_kernel(const C16Params p) {
+  constexpr int MT = WS / 32;                                 // 16-anchor tiles per wave
+  constexpr int RSTR = (WS + 2) * kDgAst;                     // floats per staged row
+  constexpr int PF = kDgRows * WS * (kDgCk / 4) / 256;        // float4 prefetched per thread and strip
+  extern __shared__ __attribute__((aligned(16))) float c16_lds[];
+  float* wl = c16_lds;
+  float* rows = c16_lds + 25 * 16 * kDgAst;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int ar = wave >> 1, mh = wave & 1;
+
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  // weights -> LDS (once per workgroup); halo columns of both row buffers -> 0 (never written again)
+  for (int i = tid; i < 25 * 16 * (kDgCk / 4); i += 256) {
+    const int r = i >> 3, q = i & 7;
+    *reinterpret_cast<float4*>(wl + r * kDgAst + q * 4) = *reinterpret_cast<const float4*>(p.Wt + (size_t)r * kDgCk + q * 4);
+  }
+  for (int i = tid; i < 2 * kDgRows * 2 * kDgAst; i += 256) {
+    const int e = i % kDgAst, side = (i / kDgAst) & 1, r = i / (2 * kDgAst);
+    rows[r * RSTR + (side ? (WS + 1) * kDgAst : 0) + e] = 0.f;
+  }
+
+  float4 pf[PF];
+  auto prefetch = [&](int strip) {
+    const int b = strip / p.strips_per_img, a0 = (strip - b * p.strips_per_img) * 2;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int item = i * 256 + tid;
+      const int r = item / (WS * 8), rem = item - r * (WS * 8);
+      const int ys = a0 - 1 + r;
+      const bool ok = strip < p.nstrips && (unsigned)ys < (unsigned)p.Hs;
+      const unsigned off = (unsigned)(((b * p.Hs + ys) * WS) * (kDgCk * 4) + rem * 16);
+      pf[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? off : kOob, 0, 0));
+    }
+  };
+  auto stash = [&](int buf) {
+    float* dst = rows + buf * kDgRows * RSTR;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int item = i * 256 + tid;
+      const int r = item / (WS * 8), rem = item - r * (WS * 8);
+      const int px = rem >> 3, q = rem & 7;
+      *reinterpret_cast<float4*>(dst + r * RSTR + (px + 1) * kDgAst + q * 4) = pf[i];
+    }
+  };
+
+  float e_bias = p.bias ? p.bias[li] : 0.f;
+  const float e_mul = p.epi_mode == BG_EPI_AFFINE_LRELU ? p.ref[li] : 1.f;
+
+  int strip = blockIdx.x;
+  prefetch(strip);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (; strip < p.nstrips; strip += gridDim.x, buf ^= 1) {
+    prefetch(strip + gridDim.x);
+    const int b = strip / p.strips_per_img, a0 = (strip - b * p.strips_per_img) * 2;
+    const int a = a0 + ar;
+    const float* rb = rows + buf * kDgRows * RSTR + (ar + 1) * RSTR + (1 + mh * (WS / 2) + li) * kDgAst + 4 * kq;
+    const float* wb = wl + li * kDgAst + 4 * kq;
+#pragma unroll
+    for (int py = 0; py < 2; ++py) {
+      floatx4 acc[2][MT];
+#pragma unroll
+      for (int px = 0; px < 2; ++px) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[px][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 5; ++kh) {
+          if (((py + 1 - kh) & 1) != 0) continue;
+          const int dy = (py + 1 - kh) / 2;
+#pragma unroll
+          for (int kw = 0; kw < 5; ++kw) {
+            if (((px + 1 - kw) & 1) != 0) continue;
+            const int dx = (px + 1 - kw) / 2;
+            const float* ap = rb + dy * RSTR + dx * kDgAst;
+            const float* bp = wb + (kh * 5 + kw) * 16 * kDgAst;
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const float4 bv = *reinterpret_cast<const float4*>(bp + 16 * h);
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) {
+                const float4 av = *reinterpret_cast<const float4*>(ap + mt * 16 * kDgAst + 16 * h);
+                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[px][mt], 0, 0, 0);
+                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[px][mt], 0, 0, 0);
+                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[px][mt], 0, 0, 0);
+                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[px][mt], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      // reg rr of lane (li, kq) = out[anchor column 16*mt + 4*kq + rr][channel li]; the two px phases are neighbouring pixels
+      if (a < p.Hs) {
+        const size_t rowbase = ((size_t)b * p.Hd + 2 * a + py) * p.Wd;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            const int c = mh * (WS / 2) + mt * 16 + 4 * kq + rr;
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+              const size_t idx = (rowbase + 2 * c + px) * 16 + li;
+              p.C[idx] = bg::apply_epilogue_pre(p, acc[px][mt][rr], idx, e_bias, e_mul);
+            }
+          }
+      }
+    }
+    stash(buf ^ 1);
+    __syncthreads();
+  }
+}
+
+void fill_epilogue(C16Params& p, const bg_epilogue* epi) {
+  p.epi_mode = BG_EPI_NONE; p.alpha = 0.3f; p.scale = 1.f;
+  if (epi) {
+    p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep; p.keep_elems = epi->keep_elems;
+    p.alpha = epi->alpha; p.scale = epi->scale;
+  }
+}
+
+}  // namespace
+
+namespace bg {
+
+// 16-channel layers of the 128x128 stacks; *taken = 0 when the shape is not covered
+int try_conv_c16(int bwd_data, const float* a, const float* w, float* c, int B, int H, int W, int Cin, int Cout, int k, int s,
+                 const bg_epilogue* epi, void* stream, int* taken) {
+  *taken = 0;
+  static const int off = getenv("BG_NO_C16") ? 1 : 0;
+  if (off || k != 5 || s != 2 || (H & 1) || (W & 1)) return BG_OK;
+  if (epi) {
+    BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "conv c16: epilogue mode %d", epi->mode);
+    BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || epi->ref, BG_ERR_NULL, "conv c16: BG_EPI_MUL_GRAD needs ref");
+    BG_REQUIRE(epi->mode != BG_EPI_AFFINE_LRELU || (epi->ref && epi->bias), BG_ERR_NULL, "conv c16: BG_EPI_AFFINE_LRELU needs ref and bias");
+  }
+  C16Params p;
+  memset(&p, 0, sizeof p);
+  if (bwd_data) {      // dy [B,H/2,W/2,Cout] -> dx [B,H,W,Cin = 16]
+    const int Hs = H / 2, Ws = W / 2;
+    if (Cin != 16 || Cout != kDgCk || (Ws != 32 && Ws != 64) || (Hs & 1)) return BG_OK;
+    if ((size_t)B * H * W * 16 >= (1ull << 29) || (size_t)B * Hs * Ws * Cout >= (1ull << 29)) return BG_OK;
+    p.A = a; p.Wt = w; p.C = c;
+    p.B = B; p.Hs = Hs; p.Ws = Ws; p.Ck = Cout; p.Hd = H; p.Wd = W; p.N = 16;
+    p.strips_per_img = Hs / 2;
+    p.nstrips = B * p.strips_per_img;
+    p.a_bytes = (unsigned)((size_t)B * Hs * Ws * Cout * sizeof(float));
+    fill_epilogue(p, epi);
+    const size_t lds = ((size_t)25 * 16 * kDgAst + (size_t)2 * kDgRows * (Ws + 2) * kDgAst) * sizeof(float);
+    const dim3 grid((unsigned)std::min(p.nstrips, 256));
+    const double flops = 2.0 * B * (double)Hs * Ws * Cin * Cout * 25;
+    Launch L(stream, "conv_c16_dgrad", flops, 0);
+    if (Ws == 64) {
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_dgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+      hipLaunchKernelGGL((conv_c16_dgrad_kernel<64>), grid, dim3(256), lds, L.s, p);
+    } else {
+      static bool attr = false;
+      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_dgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+      hipLaunchKernelGGL((conv_c16_dgrad_kernel<32>), grid, dim3(256), lds, L.s, p);
+    }
+    *taken = 1;
+    return L.done("conv_c16_dgrad_kernel");
+  }
+  return BG_OK;
+}
+
+}  // namespace bg

@@ -998,6 +998,8 @@ int bg_conv2d_bwd_data(const float* dy, const float* w_d, float* dx, int B, int 
   int rc = check_conv_args("bg_conv2d_bwd_data", dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride);
   if (rc) return rc;
   int taken = 0;
+  rc = bg::try_conv_c16(1, dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
+  if (rc || taken) return rc;
   rc = bg::try_conv_rows(1, dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
   if (rc || taken) return rc;
   rc = bg::try_conv_rows_gather(1, dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);

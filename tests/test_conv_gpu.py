@@ -22,6 +22,7 @@ CASES = [
     (2, 20, 128, 16, 3, 1), (2, 24, 256, 3, 16, 2),                           # ... on 128-pixel rows (8 waves per workgroup)
     (128, 4, 4, 64, 64, 1), (128, 8, 8, 32, 64, 2), (128, 8, 8, 64, 32, 2),   # position-major tiles: padding taps skipped (64- and 128-row tiles)
     (1024, 16, 16, 16, 32, 2),                                                 # position-major AND the four phases merged in one workgroup
+    (3, 64, 64, 16, 32, 2), (2, 128, 128, 16, 32, 2), (5, 12, 128, 16, 32, 2), (2, 4, 64, 16, 32, 2),   # row-staged 16-channel kernels (C4's outer layers)
 ]
 
 
@@ -130,6 +131,28 @@ def test_epilogues():
     np.testing.assert_allclose(dx.cpu().numpy(), exp, rtol=1e-4, atol=2 * conv_tol(25 * Co, np.abs(dxr).max()))
 
 
+def test_c16_epilogues():
+    """The row-staged 16-channel data gradient with the critic's fused LeakyReLU'/dropout product, mask on the leading samples only."""
+    from blurred_gan_amd import ops
+    from blurred_gan_amd._lib import EPI_MUL_GRAD, EPI_BIAS_LRELU
+    B, H, W, Ci, Co, s = 3, 64, 64, 16, 32, 2
+    x, w, dy = _data(B, H, W, Ci, Co, s, seed=7)
+    rng = np.random.default_rng(8)
+    ref_act = rng.normal(size=x.shape)
+    keep_x = (rng.uniform(size=x.shape) >= 0.3).astype(np.uint8)
+    dxr = O.conv2d_bwd_data(dy, w, s, (H, W))
+    n_keep = 2 * H * W * Ci
+    dx = ops.conv2d_bwd_data(dev(dy), dev(w), torch.empty(x.shape, device="cuda"), 5, s,
+                             ops.epilogue(EPI_MUL_GRAD, ref=dev(ref_act), keep=dev(keep_x, torch.uint8), alpha=0.3, scale=1 / 0.7, keep_elems=n_keep))
+    exp = dxr * O.lrelu_mask(ref_act)
+    exp[:2] *= keep_x[:2] / 0.7
+    tol = conv_tol(25 * Co, np.abs(dxr).max())
+    np.testing.assert_allclose(dx.cpu().numpy(), exp, rtol=1e-4, atol=2 * tol)
+    bias = rng.normal(size=Ci)
+    y = ops.conv2d_bwd_data(dev(dy), dev(w), torch.empty(x.shape, device="cuda"), 5, s, ops.epilogue(EPI_BIAS_LRELU, bias=dev(bias), alpha=0.3))
+    np.testing.assert_allclose(y.cpu().numpy(), O.lrelu_fwd(dxr + bias), rtol=1e-4, atol=2 * tol)
+
+
 def test_conv_transpose_roles():
     """Conv2DTranspose forward = bwd_data with the kernel array as is; its filter gradient swaps x and dy."""
     from blurred_gan_amd import ops
@@ -148,7 +171,8 @@ def test_conv_transpose_roles():
 
 
 @pytest.mark.parametrize("B,H,W,Ci,Co,s", [(256, 32, 32, 32, 64, 2), (256, 64, 64, 3, 32, 2), (256, 4, 4, 256, 512, 2),
-                                           (256, 64, 64, 32, 3, 1), (256, 16, 16, 128, 64, 2)])
+                                           (256, 64, 64, 32, 3, 1), (256, 16, 16, 128, 64, 2),
+                                           (128, 128, 128, 16, 32, 2), (384, 64, 64, 16, 32, 2)])
 def test_adjointness_full_size(B, H, W, Ci, Co, s):
     """<conv(x), dy> == <x, conv^T(dy)> == <w, wgrad(x, dy)> at the C2 layer sizes (no oracle needed)."""
     from blurred_gan_amd import ops

@@ -15,6 +15,11 @@ LAYERS = {  # (name, B-mult, H, W, Cin, Cout, stride): conv geometry (H,W,Cin = 
                  # generator ConvT layers expressed as the underlying conv (input side = ConvT output)
                  ("G1 CT512->512 s1", 4, 4, 512, 512, 1), ("G2 CT512->256", 8, 8, 256, 512, 2), ("G3 CT256->128", 16, 16, 128, 256, 2),
                  ("G4 CT128->64", 32, 32, 64, 128, 2), ("G5 CT64->32", 64, 64, 32, 64, 2), ("G6 conv32->3", 64, 64, 32, 3, 1)],
+    "celeba128": [("D1 3->16", 128, 128, 3, 16, 2), ("D2 16->32", 64, 64, 16, 32, 2), ("D3 32->64", 32, 32, 32, 64, 2),
+                  ("D4 64->128", 16, 16, 64, 128, 2), ("D5 128->256", 8, 8, 128, 256, 2), ("D6 256->512", 4, 4, 256, 512, 2),
+                  ("G1 CT512->512 s1", 4, 4, 512, 512, 1), ("G2 CT512->256", 8, 8, 256, 512, 2), ("G3 CT256->128", 16, 16, 128, 256, 2),
+                  ("G4 CT128->64", 32, 32, 64, 128, 2), ("G5 CT64->32", 64, 64, 32, 64, 2), ("G6 CT32->16", 128, 128, 16, 32, 2),
+                  ("G7 conv16->3", 128, 128, 16, 3, 1)],
 }
 
 
