@@ -88,9 +88,15 @@ __global__ __launch_bounds__(256) void conv_c16_dgrad_kernel(const C16Params p) 
     }
   };
 
-  float e_bias = p.bias ? p.bias[li] : 0.f;
-  const float e_mul = p.epi_mode == BG_EPI_AFFINE_LRELU ? p.ref[li] : 1.f;
+  float e_bias[4], e_mul[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    e_bias[rr] = p.bias ? p.bias[4 * kq + rr] : 0.f;
+    e_mul[rr] = p.epi_mode == BG_EPI_AFFINE_LRELU ? p.ref[4 * kq + rr] : 1.f;
+  }
 
+  // keep_elems is a multiple of 4 whenever it falls inside the tensor (whole samples of 16-channel pixels)
+  const int epi_kind = (p.epi_mode == BG_EPI_NONE && !p.bias) ? 0 : (p.epi_mode == BG_EPI_MUL_GRAD ? 1 : 2);
   int strip = blockIdx.x;
   prefetch(strip);
   stash(0);
@@ -125,29 +131,47 @@ __global__ __launch_bounds__(256) void conv_c16_dgrad_kernel(const C16Params p) 
 #pragma unroll
               for (int mt = 0; mt < MT; ++mt) {
                 const float4 av = *reinterpret_cast<const float4*>(ap + mt * 16 * kDgAst + 16 * h);
-                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.x, bv.x, acc[px][mt], 0, 0, 0);
-                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.y, bv.y, acc[px][mt], 0, 0, 0);
-                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.z, bv.z, acc[px][mt], 0, 0, 0);
-                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av.w, bv.w, acc[px][mt], 0, 0, 0);
+                // weights are the MFMA's row operand: D[i = channel][j = anchor], so a lane ends up with 4 consecutive channels
+                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.x, av.x, acc[px][mt], 0, 0, 0);
+                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.y, av.y, acc[px][mt], 0, 0, 0);
+                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.z, av.z, acc[px][mt], 0, 0, 0);
+                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.w, av.w, acc[px][mt], 0, 0, 0);
               }
             }
           }
         }
       }
-      // reg rr of lane (li, kq) = out[anchor column 16*mt + 4*kq + rr][channel li]; the two px phases are neighbouring pixels
-      if (a < p.Hs) {
+      // reg rr of lane (li, kq) = out[anchor column 16*mt + li][channel 4*kq + rr]: one float4 per lane, the 4 kq lanes of a
+      // pixel write its 64 bytes, and the two px phases are neighbouring pixels
+      {
         const size_t rowbase = ((size_t)b * p.Hd + 2 * a + py) * p.Wd;
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
+        for (int mt = 0; mt < MT; ++mt) {
+          const int c = mh * (WS / 2) + mt * 16 + li;
 #pragma unroll
-          for (int rr = 0; rr < 4; ++rr) {
-            const int c = mh * (WS / 2) + mt * 16 + 4 * kq + rr;
-#pragma unroll
-            for (int px = 0; px < 2; ++px) {
-              const size_t idx = (rowbase + 2 * c + px) * 16 + li;
-              p.C[idx] = bg::apply_epilogue_pre(p, acc[px][mt][rr], idx, e_bias, e_mul);
+          for (int px = 0; px < 2; ++px) {
+            const size_t idx = (rowbase + 2 * c + px) * 16 + 4 * kq;
+            const floatx4 v = acc[px][mt];
+            float4 o;
+            if (epi_kind == 0) {                               // no epilogue (ConvT -> BatchNorm): straight-line stores
+              o = make_float4(v[0], v[1], v[2], v[3]);
+            } else if (epi_kind == 1) {                        // critic data gradient: LeakyReLU' of the layer input, dropout mask
+              const float4 r = *reinterpret_cast<const float4*>(p.ref + idx);
+              float f0 = r.x > 0.f ? 1.f : p.alpha, f1 = r.y > 0.f ? 1.f : p.alpha, f2 = r.z > 0.f ? 1.f : p.alpha, f3 = r.w > 0.f ? 1.f : p.alpha;
+              if (p.keep && (p.keep_elems == 0 || idx < p.keep_elems)) {
+                const uchar4 k4 = *reinterpret_cast<const uchar4*>(p.keep + idx);
+                f0 = k4.x ? f0 * p.scale : 0.f; f1 = k4.y ? f1 * p.scale : 0.f; f2 = k4.z ? f2 * p.scale : 0.f; f3 = k4.w ? f3 * p.scale : 0.f;
+              }
+              o = make_float4((v[0] + e_bias[0]) * f0, (v[1] + e_bias[1]) * f1, (v[2] + e_bias[2]) * f2, (v[3] + e_bias[3]) * f3);
+            } else {
+              o.x = bg::apply_epilogue_pre(p, v[0], idx + 0, e_bias[0], e_mul[0]);
+              o.y = bg::apply_epilogue_pre(p, v[1], idx + 1, e_bias[1], e_mul[1]);
+              o.z = bg::apply_epilogue_pre(p, v[2], idx + 2, e_bias[2], e_mul[2]);
+              o.w = bg::apply_epilogue_pre(p, v[3], idx + 3, e_bias[3], e_mul[3]);
             }
+            *reinterpret_cast<float4*>(p.C + idx) = o;
           }
+        }
       }
     }
     stash(buf ^ 1);
