@@ -1003,6 +1003,119 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_ci_kernel(const WgradPara
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// 16 -> 32 channel, 5x5, stride-2 filter gradient (the 128x128 critic's second conv and the generator's ConvT 32 -> 16):
+//   dW[kh][kw][ci][co] = sum_{b, oy, ox} x[b, 2oy + kh - 1, 2ox + kw - 1, ci] * dy[b, oy, ox, co]
+// The tap-grouped kernel pads the 16 input channels to a 32-row MFMA tile and re-reads x once per kernel row; here the 16
+// channels ARE the rows of v_mfma_f32_16x16x4_f32, the contraction runs over 4 output pixels of a row per MFMA, and a strip's 7
+// input rows are staged in LDS once (register-prefetched, double-buffered) and serve all 25 taps.  x rows are de-interleaved by
+// column parity so that the 4 pixels of a k-step (2 columns apart) read 64 consecutive words.  Every wave keeps the full
+// 25 x 2 accumulator set (200 registers): wave w owns output row (w >> 1) of the strip and half (w & 1) of its pixels; the
+// four partial sets are summed through LDS once, at the end of the persistent loop, into the workgroup's slab.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kC16Rows = 7;
+
+template <int WO>
+__global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgradParams p, int nstrips, int strips_per_img) {
+  constexpr int W = 2 * WO, PS = (WO + 2) * 16, RS = 2 * PS, KSW = WO / 8;
+  constexpr int PFX = kC16Rows * W * 4 / 256;                // float4 of x per thread and strip
+  constexpr unsigned kOob = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) float c16_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int r = wave >> 1, half = wave & 1;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, (int)p.dy_bytes, 0x00020000);
+
+  for (int i = tid; i < 2 * kC16Rows * 2 * 2 * 16; i += 256) {   // halo slots (column -1 / -2 and W / W+1) of every plane: zero, never written
+    const int e = i & 15, side = (i >> 4) & 1, plane = i >> 5;     // plane = (buffer, row, parity)
+    c16_lds[plane * PS + (side ? (WO + 1) * 16 : 0) + e] = 0.f;
+  }
+  floatx4 acc[25][2];
+#pragma unroll
+  for (int t = 0; t < 25; ++t) { acc[t][0] = floatx4{0.f, 0.f, 0.f, 0.f}; acc[t][1] = floatx4{0.f, 0.f, 0.f, 0.f}; }
+
+  float4 pf[PFX];
+  float bn[KSW][2], bc[KSW][2];
+  auto prefetch = [&](int strip) {
+    const int b = strip / strips_per_img, oy0 = (strip - b * strips_per_img) * 2;
+    const bool live = strip < nstrips;
+#pragma unroll
+    for (int i = 0; i < PFX; ++i) {
+      const int item = i * 256 + tid;
+      const int rr = item / (W * 4), rem = item - rr * (W * 4);
+      const int y = 2 * oy0 - 1 + rr;
+      const bool ok = live && (unsigned)y < (unsigned)p.H;
+      pf[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, ok ? (unsigned)(((b * p.H + y) * W) * 64 + rem * 16) : kOob, 0, 0));
+    }
+    const unsigned ybase = (unsigned)((((b * p.Ho + oy0 + r) * WO) + half * (WO / 2) + kq) * 128 + li * 4);
+#pragma unroll
+    for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt)
+        bn[ks][nt] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsY, live ? ybase + (unsigned)(ks * 4 * 128 + nt * 64) : kOob, 0, 0));
+  };
+  auto stash = [&](int buf) {
+    float* dst = c16_lds + buf * kC16Rows * RS;
+#pragma unroll
+    for (int i = 0; i < PFX; ++i) {
+      const int item = i * 256 + tid;
+      const int rr = item / (W * 4), rem = item - rr * (W * 4);
+      const int x = rem >> 2, q = rem & 3;
+      *reinterpret_cast<float4*>(dst + rr * RS + (x & 1) * PS + ((x >> 1) + 1) * 16 + q * 4) = pf[i];
+    }
+  };
+
+  int strip = blockIdx.x;
+  prefetch(strip);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (; strip < nstrips; strip += gridDim.x, buf ^= 1) {
+#pragma unroll
+    for (int ks = 0; ks < KSW; ++ks) { bc[ks][0] = bn[ks][0]; bc[ks][1] = bn[ks][1]; }
+    prefetch(strip + gridDim.x);
+    const float* xb = c16_lds + buf * kC16Rows * RS + (2 * r) * RS + (half * (WO / 2) + kq + 1) * 16 + li;
+#pragma unroll
+    for (int ks = 0; ks < KSW; ++ks)
+#pragma unroll
+      for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 5; ++kw) {
+          // column 2*ox + kw - 1: parity (kw + 1) & 1, half-column ox + floor((kw - 1) / 2)
+          const int par = (kw + 1) & 1, fl = kw == 0 ? -1 : (kw - 1) / 2;
+          const float a = xb[kh * RS + par * PS + (4 * ks + fl) * 16];
+          acc[kh * 5 + kw][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[ks][0], acc[kh * 5 + kw][0], 0, 0, 0);
+          acc[kh * 5 + kw][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bc[ks][1], acc[kh * 5 + kw][1], 0, 0, 0);
+        }
+    stash(buf ^ 1);
+    __syncthreads();
+  }
+  // cross-wave sum in wave order (deterministic); reg rr of lane l = D[ci = 4*(l>>4) + rr][co = l & 15]
+  float* red = c16_lds;                                       // [25*2*4][64]
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int t = 0; t < 25; ++t)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+          for (int rr = 0; rr < 4; ++rr) {
+            float* q = red + ((t * 2 + nt) * 4 + rr) * 64 + lane;
+            *q = (w == 0 ? 0.f : *q) + acc[t][nt][rr];
+          }
+    }
+  }
+  __syncthreads();
+  float* out = p.out + (size_t)blockIdx.x * 25 * 16 * 32;
+  for (int e = tid; e < 25 * 2 * 4 * 64; e += 256) {
+    const int l = e & 63, slot = e >> 6;
+    const int rr = slot & 3, nt = (slot >> 2) & 1, t = slot >> 3;
+    out[(size_t)(t * 16 + 4 * (l >> 4) + rr) * 32 + nt * 16 + (l & 15)] = red[e];
+  }
+}
+
 // dw = beta*dw + scale * sum_z slabs[z]; block = 64 float4 columns x 4 slab groups (LDS tree), so few-output layers
 // with many slabs still expose enough parallelism
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int n,
@@ -1102,6 +1215,16 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
     long chunk = std::max(256L, (M + want - 1) / want);
     pl.chunk = (int)chunk;
     pl.ksplit = (int)((M + chunk - 1) / chunk);
+    return pl;
+  }
+  if (Ci == 16 && Co == 32 && k == 5 && s == 2 && !(H & 1) && !(W & 1) && (Wo == 32 || Wo == 64) && !(Ho & 1) && !getenv("BG_NO_C16")) {
+    pl.mode = 32;                                             // row-staged 16-channel kernel, persistent workgroups, one slab each
+    pl.bkp = 4;
+    const long nstrips = (long)B * (Ho / 2);
+    pl.ksplit = (int)std::max<long>(2, std::min<long>(nstrips, 256));
+    pl.chunk = (int)nstrips;
+    pl.tiles_m = pl.tiles_n = 1;
+    pl.taps_in_grid = 0;
     return pl;
   }
   if (thin_ci && k * Ci <= 16 && (k == 5 || k == 3) && (Co == 16 || Co == 32 || Co == 64) && Wo % 4 == 0 && !getenv("BG_WGRAD_NO_TC")) {
@@ -1265,6 +1388,19 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     bg::Launch L(stream, "conv_wgrad_direct", flops, 0);
     hipLaunchKernelGGL(wgrad_direct_kernel, dim3(bg::cdiv(nout, 256), pl.ksplit), dim3(256), 0, L.s, p);
     rc = L.done("wgrad_direct_kernel");
+  } else if (pl.mode == 32) {
+    bg::Launch L(stream, "conv_wgrad_c16", flops, 0);
+    const int spi = p.Ho / 2, nstrips = B * spi;
+    const size_t lds = std::max((size_t)2 * kC16Rows * 2 * (p.Wo + 2) * 16, (size_t)25 * 2 * 4 * 64) * sizeof(float);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_c16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_c16_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr = true;
+    }
+    if (p.Wo == 64) hipLaunchKernelGGL((conv_wgrad_c16_kernel<64>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nstrips, spi);
+    else hipLaunchKernelGGL((conv_wgrad_c16_kernel<32>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nstrips, spi);
+    rc = L.done("conv_wgrad_c16_kernel");
   } else if (pl.mode == 31) {
     bg::Launch L(stream, "conv_wgrad_mfma_thin_ci", flops, 0);
     const int rb = stride == 2 ? 8 : 16;
