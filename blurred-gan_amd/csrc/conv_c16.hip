@@ -179,6 +179,122 @@ __global__ __launch_bounds__(256) void conv_c16_dgrad_kernel(const C16Params p) 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// forward, Ck = 16 input channels, N = 32, k = 5, s = 2, even H and W:
+//   out[b, oy, ox, n] = sum_{kh, kw, c} x[b, 2oy + kh - 1, 2ox + kw - 1, c] * wT[kh*5 + kw][n][c]
+// (also the data gradient of ConvT 32 -> 16).  A strip is 2 output rows = 7 input rows, staged de-interleaved by column parity
+// (the 16 pixels of an MFMA tile are then 16 consecutive 20-float slots: conflict-free b128 reads).  No weight LDS: wave w works
+// on output-channel tile (w & 1) and keeps its 25 weight fragments in registers; it owns output row (w >> 1) of the strip.
+// ------------------------------------------------------------------------------------------------------------------------
+constexpr int kFwRows = 7, kFwPst = 20;
+
+template <int WO>
+__global__ __launch_bounds__(256) void conv_c16_fwd_kernel(const C16Params p) {
+  constexpr int W = 2 * WO, MT = WO / 16;
+  constexpr int PS = (WO + 2) * kFwPst, RS = 2 * PS;
+  constexpr int PF = kFwRows * W * 4 / 256;
+  extern __shared__ __attribute__((aligned(16))) float c16_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, kq = lane >> 4;
+  const int nt = wave & 1, r = wave >> 1;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+
+  for (int i = tid; i < 2 * kFwRows * 2 * 2 * kFwPst; i += 256) {   // halo slots of every parity plane: zero, never written again
+    const int e = i % kFwPst, side = (i / kFwPst) & 1, plane = i / (2 * kFwPst);
+    c16_lds[plane * PS + (side ? (WO + 1) * kFwPst : 0) + e] = 0.f;
+  }
+  float4 wf[25];                                              // row operand: lane (li, kq) = wT[tap][16*nt + li][4*kq .. 4*kq+3]
+#pragma unroll
+  for (int t = 0; t < 25; ++t) wf[t] = *reinterpret_cast<const float4*>(p.Wt + ((size_t)t * 32 + nt * 16 + li) * 16 + 4 * kq);
+
+  float4 pf[PF];
+  auto prefetch = [&](int strip) {
+    const int b = strip / p.strips_per_img, oy0 = (strip - b * p.strips_per_img) * 2;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int item = i * 256 + tid;
+      const int rr = item / (W * 4), rem = item - rr * (W * 4);
+      const int y = 2 * oy0 - 1 + rr;
+      const bool ok = strip < p.nstrips && (unsigned)y < (unsigned)p.Hs;
+      pf[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? (unsigned)(((b * p.Hs + y) * W) * 64 + rem * 16) : kOob, 0, 0));
+    }
+  };
+  auto stash = [&](int buf) {
+    float* dst = c16_lds + buf * kFwRows * RS;
+#pragma unroll
+    for (int i = 0; i < PF; ++i) {
+      const int item = i * 256 + tid;
+      const int rr = item / (W * 4), rem = item - rr * (W * 4);
+      const int x = rem >> 2, q = rem & 3;
+      *reinterpret_cast<float4*>(dst + rr * RS + (x & 1) * PS + ((x >> 1) + 1) * kFwPst + q * 4) = pf[i];
+    }
+  };
+
+  float e_bias[4], e_mul[4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    e_bias[rr] = p.bias ? p.bias[nt * 16 + 4 * kq + rr] : 0.f;
+    e_mul[rr] = p.epi_mode == BG_EPI_AFFINE_LRELU ? p.ref[nt * 16 + 4 * kq + rr] : 1.f;
+  }
+  const int epi_kind = (p.epi_mode == BG_EPI_NONE && !p.bias) ? 0 : (p.epi_mode == BG_EPI_BIAS_LRELU ? 1 : 2);
+
+  int strip = blockIdx.x;
+  prefetch(strip);
+  stash(0);
+  __syncthreads();
+  int buf = 0;
+  for (; strip < p.nstrips; strip += gridDim.x, buf ^= 1) {
+    prefetch(strip + gridDim.x);
+    const int b = strip / p.strips_per_img, oy = (strip - b * p.strips_per_img) * 2 + r;
+    const float* xb = c16_lds + buf * kFwRows * RS + (2 * r) * RS + (li + 1) * kFwPst + 4 * kq;
+    floatx4 acc[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) acc[mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < 5; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 5; ++kw) {
+        const int par = (kw + 1) & 1, fl = kw == 0 ? -1 : (kw - 1) / 2;
+        const float4 wv = wf[kh * 5 + kw];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const float4 xv = *reinterpret_cast<const float4*>(xb + kh * RS + par * PS + (mt * 16 + fl) * kFwPst);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[mt], 0, 0, 0);
+          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[mt], 0, 0, 0);
+        }
+      }
+    // reg rr of lane (li, kq) = out[pixel 16*mt + li][channel 16*nt + 4*kq + rr]
+    const size_t rowbase = ((size_t)b * p.Hd + oy) * WO;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const size_t idx = (rowbase + mt * 16 + li) * 32 + nt * 16 + 4 * kq;
+      const floatx4 v = acc[mt];
+      float4 o;
+      if (epi_kind == 0) {
+        o = make_float4(v[0], v[1], v[2], v[3]);
+      } else if (epi_kind == 1) {                            // critic forward: bias, LeakyReLU, dropout mask
+        float t0 = v[0] + e_bias[0], t1 = v[1] + e_bias[1], t2 = v[2] + e_bias[2], t3 = v[3] + e_bias[3];
+        t0 = t0 > 0.f ? t0 : p.alpha * t0; t1 = t1 > 0.f ? t1 : p.alpha * t1; t2 = t2 > 0.f ? t2 : p.alpha * t2; t3 = t3 > 0.f ? t3 : p.alpha * t3;
+        if (p.keep && (p.keep_elems == 0 || idx < p.keep_elems)) {
+          const uchar4 k4 = *reinterpret_cast<const uchar4*>(p.keep + idx);
+          t0 = k4.x ? t0 * p.scale : 0.f; t1 = k4.y ? t1 * p.scale : 0.f; t2 = k4.z ? t2 * p.scale : 0.f; t3 = k4.w ? t3 * p.scale : 0.f;
+        }
+        o = make_float4(t0, t1, t2, t3);
+      } else {
+        o.x = bg::apply_epilogue_pre(p, v[0], idx + 0, e_bias[0], e_mul[0]);
+        o.y = bg::apply_epilogue_pre(p, v[1], idx + 1, e_bias[1], e_mul[1]);
+        o.z = bg::apply_epilogue_pre(p, v[2], idx + 2, e_bias[2], e_mul[2]);
+        o.w = bg::apply_epilogue_pre(p, v[3], idx + 3, e_bias[3], e_mul[3]);
+      }
+      *reinterpret_cast<float4*>(p.C + idx) = o;
+    }
+    stash(buf ^ 1);
+    __syncthreads();
+  }
+}
+
 void fill_epilogue(C16Params& p, const bg_epilogue* epi) {
   p.epi_mode = BG_EPI_NONE; p.alpha = 0.3f; p.scale = 1.f;
   if (epi) {
@@ -230,7 +346,32 @@ int try_conv_c16(int bwd_data, const float* a, const float* w, float* c, int B, 
     *taken = 1;
     return L.done("conv_c16_dgrad_kernel");
   }
-  return BG_OK;
+  // forward: x [B,H,W,16] -> y [B,H/2,W/2,32]
+  {
+    const int Ho = H / 2, Wo = W / 2;
+    if (Cin != 16 || Cout != 32 || (Wo != 32 && Wo != 64) || (Ho & 1)) return BG_OK;
+    if ((size_t)B * H * W * 16 >= (1ull << 29) || (size_t)B * Ho * Wo * 32 >= (1ull << 29)) return BG_OK;
+    p.A = a; p.Wt = w; p.C = c;
+    p.B = B; p.Hs = H; p.Ws = W; p.Ck = 16; p.Hd = Ho; p.Wd = Wo; p.N = 32;
+    p.strips_per_img = Ho / 2;
+    p.nstrips = B * p.strips_per_img;
+    p.a_bytes = (unsigned)((size_t)B * H * W * 16 * sizeof(float));
+    fill_epilogue(p, epi);
+    const size_t lds = (size_t)2 * kFwRows * 2 * (Wo + 2) * kFwPst * sizeof(float);
+    const dim3 grid((unsigned)std::min(p.nstrips, 256));
+    const double flops = 2.0 * B * (double)Ho * Wo * Cin * Cout * 25;
+    Launch L(stream, "conv_c16_fwd", flops, 0);
+    static bool attr = false;
+    if (!attr) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+      attr = true;
+    }
+    if (Wo == 64) hipLaunchKernelGGL((conv_c16_fwd_kernel<64>), grid, dim3(256), lds, L.s, p);
+    else hipLaunchKernelGGL((conv_c16_fwd_kernel<32>), grid, dim3(256), lds, L.s, p);
+    *taken = 1;
+    return L.done("conv_c16_fwd_kernel");
+  }
 }
 
 }  // namespace bg

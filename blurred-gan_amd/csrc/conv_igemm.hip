@@ -982,6 +982,8 @@ int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int
   int rc = check_conv_args("bg_conv2d_fwd", x, wT_d, y, B, H, W, Cin, Cout, ksize, stride);
   if (rc) return rc;
   int taken = 0;
+  rc = bg::try_conv_c16(0, x, wT_d, y, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
+  if (rc || taken) return rc;
   rc = bg::try_conv_rows(0, x, wT_d, y, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
   if (rc || taken) return rc;
   rc = bg::try_conv_rows_gather(0, x, wT_d, y, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);

@@ -151,6 +151,20 @@ def test_c16_epilogues():
     bias = rng.normal(size=Ci)
     y = ops.conv2d_bwd_data(dev(dy), dev(w), torch.empty(x.shape, device="cuda"), 5, s, ops.epilogue(EPI_BIAS_LRELU, bias=dev(bias), alpha=0.3))
     np.testing.assert_allclose(y.cpu().numpy(), O.lrelu_fwd(dxr + bias), rtol=1e-4, atol=2 * tol)
+    # forward 16 -> 32 with the critic's fused bias + LeakyReLU + dropout (mask on the first two samples), and with tanh (generic path)
+    from blurred_gan_amd._lib import EPI_TANH
+    bias_o = rng.normal(size=Co)
+    z = O.conv2d_fwd(x, w, s) + bias_o
+    keep_y = (rng.uniform(size=z.shape) >= 0.3).astype(np.uint8)
+    wT = dev(np.transpose(w, (0, 1, 3, 2)))
+    tolf = conv_tol(25 * Ci, np.abs(z).max())
+    yk = ops.conv2d_fwd(dev(x), wT, torch.empty(z.shape, device="cuda"), 5, s,
+                        ops.epilogue(EPI_BIAS_LRELU, bias=dev(bias_o), keep=dev(keep_y, torch.uint8), alpha=0.3, scale=1 / 0.7, keep_elems=2 * z[0].size))
+    expf = O.lrelu_fwd(z)
+    expf[:2] = expf[:2] * keep_y[:2] / 0.7
+    np.testing.assert_allclose(yk.cpu().numpy(), expf, rtol=1e-4, atol=2 * tolf)
+    yt = ops.conv2d_fwd(dev(x), wT, torch.empty(z.shape, device="cuda"), 5, s, ops.epilogue(EPI_TANH, bias=dev(bias_o)))
+    np.testing.assert_allclose(yt.cpu().numpy(), np.tanh(z), rtol=1e-4, atol=tolf)
 
 
 def test_conv_transpose_roles():
