@@ -125,7 +125,9 @@ def main():
         for name, ms, fl, by in recs:
             k = kern.setdefault(name, [0, 0.0, 0.0, 0.0])
             k[0] += 1; k[1] += ms; k[2] += fl; k[3] += by
-        mfma = {n: k for n, k in kern.items() if n.startswith("conv_igemm") or n.startswith("conv_wgrad_mfma")}
+        # every conv kernel family runs on the MFMA pipe (gather-GEMM, row-staged, filter-gradient) except the direct fallback;
+        # their split-K / slab reduce passes are counted with them
+        mfma = {n: k for n, k in kern.items() if n.startswith("conv_") and n != "conv_wgrad_direct"}
         if mfma:
             dom = max(mfma, key=lambda n: mfma[n][1])
             cnt, ms, fl, _ = mfma[dom]
