@@ -24,6 +24,13 @@ def world_size():
     return td.get_world_size() if is_initialized() else 1
 
 
+def collectives_active():
+    """True when gradient / BatchNorm-statistics exchange has to run: more than one replica, or a one-rank group with
+    BGAN_DP_FORCE_COLLECTIVES=1 (the RCCL rehearsal of tests/test_dp_gpu.py on a one-GPU box: every collective is issued
+    and waited for exactly as with N ranks, its result is the identity)."""
+    return world_size() > 1 or (is_initialized() and os.environ.get("BGAN_DP_FORCE_COLLECTIVES") == "1")
+
+
 def local_rank():
     """Device index of this process.  One process per GPU; when a node exposes fewer devices than ranks (the
     2-ranks-on-one-card rehearsal of tests/test_dp_gpu.py and of bench.py) ranks share devices round-robin."""
@@ -35,7 +42,8 @@ def local_rank():
 def init_from_env(backend=None):
     """Joins the process group described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
     ws = int(os.environ.get("WORLD_SIZE", "1"))
-    if ws <= 1 or is_initialized():
+    forced = os.environ.get("BGAN_DP_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ   # one-rank rehearsal of the collective path
+    if (ws <= 1 and not forced) or is_initialized():
         return world_size()
     use_cuda = torch.cuda.is_available()
     if use_cuda:
@@ -49,7 +57,7 @@ def init_from_env(backend=None):
 
 def all_reduce_sum_(flat):
     """In-place SUM all-reduce of a flat gradient buffer (no-op for a single replica)."""
-    if world_size() > 1:
+    if collectives_active():
         if _use_abi_comm(flat):
             AbiComm.get().all_reduce_async(flat).wait()
         elif flat.is_cuda and td.get_backend() == "gloo":    # CPU test harness: stage through the host
@@ -131,7 +139,7 @@ class GradReducer:
     def __init__(self, flat, n, bucket_bytes=4 << 20):
         self.flat, self.n = flat, int(n)
         self.bucket = max(1, int(bucket_bytes) // 4)
-        self.active = world_size() > 1
+        self.active = collectives_active()
         self.pending = None          # (lo, hi) merged, not yet issued
         self.covered = []            # issued ranges
         self.works = []

@@ -316,7 +316,7 @@ class Net:
                 C = st.out_shape[-1]
                 M = tgt.numel() // C
                 bn = st.bn
-                if training and self.sync_bn and dist.world_size() > 1:
+                if training and self.sync_bn and dist.collectives_active():
                     # SyncBN: batch statistics over the GLOBAL batch -- all-reduce the per-channel sums
                     ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
                     sums = ctx.bn_sums(i, C)
@@ -369,7 +369,7 @@ class Net:
                 ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
                 dg = st_.grad_of(st.bn, "gamma") if need_dw else torch.empty(C, device=self.device)
                 db = st_.grad_of(st.bn, "beta") if need_dw else torch.empty(C, device=self.device)
-                if self.sync_bn and dist.world_size() > 1:
+                if self.sync_bn and dist.collectives_active():
                     world = dist.world_size()
                     sums = ctx.bn_sums(i, C)
                     ops.bn_bwd_stats(gv, ctx.a[i], ctx.z[i], M, C, ctx.mean[i], ctx.inv[i], sums, ws, lrelu_alpha=st.alpha)

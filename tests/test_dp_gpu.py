@@ -119,3 +119,41 @@ def test_abi_communicator_argument_errors():
     assert lib.bg_comm_init(None, 0, 1, b"\0" * 128) == -6
     assert lib.bg_allreduce_sum_f32(None, None, 4, None) == -6
     assert lib.bg_comm_destroy(None) == 0
+
+
+def _rccl_worker(rank, port, out_dir):
+    os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      BGAN_DP_FORCE_COLLECTIVES="1")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from blurred_gan_amd import dist
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group(backend="nccl")             # RCCL, one rank
+    assert dist.collectives_active()
+    gan, reals, rnd = _build("tiny", 6, 6)
+    for _ in range(2):
+        gan.train_on_batch(reals, randomness=rnd)
+    torch.cuda.synchronize()
+    for tag, net in (("d", gan.discriminator), ("g", gan.generator)):
+        st = net.store
+        np.save(os.path.join(out_dir, f"rccl_{tag}_theta.npy"), st.theta[:st.n_train].cpu().numpy())
+        np.save(os.path.join(out_dir, f"rccl_{tag}_grad.npy"), st.grad[:st.n_train].cpu().numpy())
+    assert dist.max_over_ranks(3.5) == 3.5
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_rccl_path_single_rank_matches_plain_step(tmp_path):
+    """The production collective path on real RCCL (backend "nccl"), with the one rank the test box has: bucketed asynchronous
+    gradient all-reduces overlapped with the backward, SyncBN statistics exchange, wait-before-Adam.  Every collective is the
+    identity here, so two training steps must land on the weights of the plain single-process steps."""
+    mp.spawn(_rccl_worker, args=(_free_port(), str(tmp_path)), nprocs=1, join=True)
+    gan, reals, rnd = _build("tiny", 6, 6)
+    for _ in range(2):
+        gan.train_on_batch(reals, randomness=rnd)
+    for tag, net in (("d", gan.discriminator), ("g", gan.generator)):
+        st = net.store
+        ref_t, ref_g = st.theta[:st.n_train].cpu().numpy(), st.grad[:st.n_train].cpu().numpy()
+        got_t, got_g = np.load(tmp_path / f"rccl_{tag}_theta.npy"), np.load(tmp_path / f"rccl_{tag}_grad.npy")
+        np.testing.assert_allclose(got_g, ref_g, rtol=2e-3, atol=2e-4 * np.abs(ref_g).max())
+        np.testing.assert_allclose(got_t, ref_t, rtol=1e-3, atol=2e-4)
