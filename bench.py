@@ -164,6 +164,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_sample_batch)
         print(json.dumps(out), flush=True)
     dist.barrier()
+    dist.shutdown()
 
 
 if __name__ == "__main__":

@@ -226,6 +226,14 @@ def barrier():
         td.barrier()
 
 
+def shutdown():
+    """Leaves the process group (no-op when none was joined): RCCL communicators are torn down before interpreter exit."""
+    if AbiComm._inst is not None:
+        AbiComm._inst.close()
+    if is_initialized():
+        td.destroy_process_group()
+
+
 def shard(batch, r=None, n=None):
     """The slice of a global batch this replica trains on (equal shards)."""
     r = rank() if r is None else r
