@@ -206,7 +206,6 @@ __global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restric
   constexpr int PX = 32 / C, NQ = PX * C;                      // whole pixels / columns per MFMA tile
   const int r0 = rg * kBtRows, s0 = cg * 4 * PX;
   const int q0 = s0 * C, ncols = min(4 * NQ, Q - q0);          // this workgroup's source / output columns
-  const int rw0 = r0 + 32 * wave;                              // this wave's first output row
   const int li = lane & 31, kk = lane >> 5;
   const float* xi = x + (size_t)b * R * Q;
   float* yi = y + (size_t)b * R * Q;
@@ -216,7 +215,6 @@ __global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restric
 #pragma unroll
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
   const int k_lo = max(0, r0 - half) / kBtChunk * kBtChunk, k_hi = min(R, r0 + kBtRows + half);
-  const int my_lo = rw0 - half, my_hi = rw0 + 32 + half;      // source rows this wave's block needs
   const bool vec4 = (Q & 3) == 0 && (ncols & 3) == 0;
   // chunk loader: 32 rows x ncols floats, row-contiguous in global memory
   float4 g[4];
@@ -250,18 +248,24 @@ __global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restric
   gload(k_lo);
   lstore(0, k_lo);
   __syncthreads();
-  const float* ta = tz + kBtPad + half - (rw0 + li) + kk;      // + k
+  // wave w owns column tile w of the workgroup (NQ columns) for all four 32-row blocks: every wave has the same band structure,
+  // so no wave idles at the chunk barriers while another works through its band
+  const float* ta0 = tz + kBtPad + half - (r0 + li) + kk;     // + k - 32*jb
   int buf = 0;
   for (int kc = k_lo; kc < k_hi; kc += kBtChunk, buf ^= 1) {
     const bool more = kc + kBtChunk < k_hi;
     if (more) gload(kc + kBtChunk);                            // next chunk's loads fly under this chunk's MFMAs
-    if (rw0 < R && kc + kBtChunk > my_lo && kc < my_hi) {      // wave-uniform: chunk inside this wave's band
-      const float* bb = Bs + buf * kBtChunk * kBtStride + kk * kBtStride + li;
-#pragma unroll 4
-      for (int kp = 0; kp < kBtChunk / 2; ++kp) {
-        const float a = ta[kc + 2 * kp];
+    {
+      const float* bb = Bs + buf * kBtChunk * kBtStride + kk * kBtStride + wave * NQ + li;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, bb[2 * kp * kBtStride + j * NQ], acc[j], 0, 0, 0);
+      for (int jb = 0; jb < 4; ++jb) {
+        // the k-pairs of this chunk inside the band of row block jb (rows r0 + 32*jb - half .. r0 + 32*jb + 31 + half)
+        const int lo = r0 + 32 * jb - half, hi = r0 + 32 * jb + 32 + half;
+        const int kp_lo = max(0, (lo - kc) >> 1), kp_hi = min(kBtChunk / 2, (hi - kc + 1) >> 1);
+        if (r0 + 32 * jb >= R) continue;
+        const float* ta = ta0 - 32 * jb + kc;
+        for (int kp = kp_lo; kp < kp_hi; ++kp)
+          acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[2 * kp], bb[2 * kp * kBtStride], acc[jb], 0, 0, 0);
       }
     }
     if (more) lstore(buf ^ 1, kc + kBtChunk);
@@ -269,19 +273,39 @@ __global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restric
   }
   // transposed store: tile element (r, q = pixel*C + c) -> out[(pixel*R + r)*C + c]; through this wave's LDS tile (the chunk
   // buffers are free after the last barrier) so that the 32*C floats of one pixel column leave contiguously
-  float* tt = Bs + wave * 32 * 33;
-  if (rw0 >= R) return;
-  const int nrow = min(32, R - rw0);
+  constexpr int RUN = 32 * C + 4;                              // one pixel column of the transposed tile (32 rows x C) + pad
+  constexpr int TSZ = PX * RUN > 32 * 33 ? PX * RUN : 32 * 33; // per-wave transpose area, the same for both layouts below
+  static_assert(4 * TSZ <= 2 * kBtChunk * kBtStride, "transpose tiles must fit the chunk buffers");
+  const int sp0 = s0 + wave * PX;                              // first pixel column of this wave's tile
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int jb = 0; jb < 4; ++jb) {
+    const int rw0 = r0 + 32 * jb;
+    if (rw0 >= R) break;
+    const int nrow = min(32, R - rw0);
+    if (nrow == 32 && ((R * C) & 3) == 0) {
+      // tile element (r, px, c) -> tt[px][r*C + c]: a pixel column is 32*C contiguous floats in the output, read back as float4
+      float* tt = Bs + wave * TSZ;
+      const int px_l = li / C, c_l = li - px_l * C;
+      if (li < NQ) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) tt[((q & 3) + 8 * (q >> 2) + 4 * kk) * 33 + li] = acc[j][q];
-    // same wave writes and reads: LDS executes a wave's operations in order
-    for (int e = lane; e < PX * 32 * C; e += 64) {
-      const int px = e / (32 * C), rem = e - px * 32 * C;
-      const int r = rem / C, c = rem - r * C;
-      const int sp = s0 + j * PX + px;
-      if (sp < S && r < nrow) yi[((size_t)sp * R + rw0 + r) * C + c] = tt[r * 33 + px * C + c];
+        for (int q = 0; q < 16; ++q) tt[px_l * RUN + ((q & 3) + 8 * (q >> 2) + 4 * kk) * C + c_l] = acc[jb][q];
+      }
+      // same wave writes and reads: LDS executes a wave's operations in order
+      for (int f = lane; f < PX * 8 * C; f += 64) {
+        const int px = f / (8 * C), w4 = f - px * 8 * C;
+        const int sp = sp0 + px;
+        if (sp < S) *reinterpret_cast<float4*>(yi + ((size_t)sp * R + rw0) * C + 4 * w4) = *reinterpret_cast<const float4*>(tt + px * RUN + 4 * w4);
+      }
+    } else {
+      float* tt = Bs + wave * TSZ;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) tt[((q & 3) + 8 * (q >> 2) + 4 * kk) * 33 + li] = acc[jb][q];
+      for (int e = lane; e < PX * 32 * C; e += 64) {
+        const int px = e / (32 * C), rem = e - px * 32 * C;
+        const int r = rem / C, c = rem - r * C;
+        const int sp = sp0 + px;
+        if (sp < S && r < nrow) yi[((size_t)sp * R + rw0 + r) * C + c] = tt[r * 33 + px * C + c];
+      }
     }
   }
 }
@@ -443,11 +467,30 @@ int bg_gauss_kernel_1d(float sigma_eff, float kernel_size, float* taps_host, int
   return BG_OK;
 }
 
+// Which kernel family a blur call takes (bg_blur_workspace_bytes and bg_blur_nhwc_f32 must agree on the scratch image):
+//   0 whole image per workgroup on the matrix cores (<= 64x64, >= 13 taps)     -- no scratch
+//   1 whole image per workgroup, register sliding window (fits LDS, < 13 taps)  -- no scratch
+//   2 two transposing banded-Toeplitz passes (C <= 4)                           -- scratch
+//   3 line kernels / generic passes                                             -- scratch
+static int blur_path(int B, int H, int W, int C, int n_taps) {
+  static const int mfma_min_taps = getenv("BG_BLUR_MFMA_MIN_TAPS") ? atoi(getenv("BG_BLUR_MFMA_MIN_TAPS")) : 13;
+  static const int band_t_min = getenv("BG_BLUR_BANDT_MIN_TAPS") ? atoi(getenv("BG_BLUR_BANDT_MIN_TAPS")) : 13;
+  const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
+  const size_t lds_m = ((size_t)2 * C * Hp * (Wp + 1) + n_taps + 2 * kTzPad) * sizeof(float);
+  if (H <= 64 && W <= 64 && C <= 16 && n_taps >= mfma_min_taps && lds_m <= kFusedLdsCap) return 0;
+  const bool fused_fits = fused_lds_bytes(H, W, C) <= kFusedLdsCap && n_taps <= 500;
+  const bool band_ok = C <= 4 && (size_t)B * H * W * C < (1ull << 31);
+  // measured (tools/blur_sweep.py): the band kernels beat the line kernels at every tap count (128x128x3: 38-43 us against
+  // 43-68; 256x256x3: 60-72 against 97-170)
+  // ... and the sliding-window fused kernel from about 31 taps up (128x128x1: 28 us both at 31 taps, 37 against 77 at 129)
+  if (fused_fits && !(band_ok && n_taps >= std::max(band_t_min, 31) && (H > 64 || W > 64))) return 1;
+  if (band_ok) return 2;
+  return 3;
+}
+
 size_t bg_blur_workspace_bytes(int B, int H, int W, int C, int n_taps) {
-  (void)n_taps;
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-  if (fused_lds_bytes(H, W, C) <= kFusedLdsCap && n_taps <= 500) return 0;
-  return (size_t)B * H * W * C * sizeof(float);
+  return blur_path(B, H, W, C, n_taps) <= 1 ? 0 : (size_t)B * H * W * C * sizeof(float);
 }
 
 int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const float* taps_d, int n_taps,
@@ -459,11 +502,11 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   const size_t total = (size_t)B * H * W * C;
   const double flops = 4.0 * n_taps * (double)total, bytes = 8.0 * (double)total;
   hipStream_t s = static_cast<hipStream_t>(stream);
+  const int path = blur_path(B, H, W, C, n_taps);
   {
-    static const int mfma_min_taps = getenv("BG_BLUR_MFMA_MIN_TAPS") ? atoi(getenv("BG_BLUR_MFMA_MIN_TAPS")) : 13;
     const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
     const size_t lds_m = ((size_t)2 * C * Hp * (Wp + 1) + n_taps + 2 * kTzPad) * sizeof(float);
-    if (H <= 64 && W <= 64 && C <= 16 && n_taps >= mfma_min_taps && lds_m <= kFusedLdsCap) {
+    if (path == 0) {
       static bool attr_m = false;
       if (!attr_m) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsCap);
@@ -485,7 +528,7 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
     }
   }
   const size_t lds = fused_lds_bytes(H, W, C);
-  if (lds <= kFusedLdsCap && n_taps <= 500) {
+  if (path == 1) {
     static bool attr_set = false;
     if (!attr_set) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_fused_kernel),
@@ -502,11 +545,9 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   const int WC = W * C;
   {
     // two transposing banded-Toeplitz passes on the matrix cores: x[H][W][C] -> tmp[W][H][C] -> y[H][W][C].
-    // measured (64 x 256x256x3): 31 / 143 / 255 taps 0.13 / 0.21 / 0.26 ms against 0.17 / 0.47 / 0.67 for the line kernels;
-    // 128x128 at 31 taps 0.089 against 0.069 -> line kernels keep the small-image, narrow-kernel corner.
-    static const int band_t_min = getenv("BG_BLUR_BANDT_MIN_TAPS") ? atoi(getenv("BG_BLUR_BANDT_MIN_TAPS")) : 48;
-    const bool big = H >= 192 && W >= 192;
-    if ((n_taps >= band_t_min || (big && n_taps >= 13)) && C <= 4 && (size_t)B * H * WC < (1ull << 31)) {
+    // measured (64 x 256x256x3): 31 / 143 / 255 taps 0.075 / 0.126 / 0.160 ms against 0.17 / 0.47 / 0.67 for the line kernels;
+    // 128 x 128x128x3 at 31 taps 0.043 against 0.068.
+    if (path == 2) {
       const int PX = 32 / C;
       const size_t lds_t = ((size_t)((n_taps + 2 * kBtPad + 3) & ~3) + 2 * kBtChunk * kBtStride) * sizeof(float);
       for (int pass = 0; pass < 2; ++pass) {

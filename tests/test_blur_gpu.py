@@ -25,7 +25,8 @@ def _run(x, std):
     ((3, 8, 8, 3), 0.05), ((2, 28, 28, 1), 0.05), ((2, 28, 28, 1), 23.5), ((4, 64, 64, 3), 5.0), ((2, 64, 64, 3), 4.94),
     ((2, 64, 64, 3), 0.5), ((2, 9, 13, 3), 1.0), ((1, 128, 128, 3), 5.0), ((2, 128, 128, 3), 23.5), ((1, 256, 256, 3), 23.5),
     ((1, 256, 256, 3), 42.34), ((2, 12, 12, 1), 0.7), ((2, 5, 7, 2), 2.0),
-    ((2, 100, 72, 3), 3.0), ((1, 218, 178, 3), 5.0), ((3, 96, 80, 1), 8.0), ((2, 130, 66, 2), 30.0), ((1, 218, 178, 3), 40.0),   # line kernels / banded Toeplitz passes (>= 100 taps), ragged blocks
+    ((2, 100, 72, 3), 3.0), ((1, 218, 178, 3), 5.0), ((3, 96, 80, 1), 8.0), ((2, 130, 66, 2), 30.0), ((1, 218, 178, 3), 40.0),
+    ((2, 128, 128, 4), 5.0), ((3, 160, 144, 1), 6.0), ((2, 128, 128, 3), 1.0), ((2, 192, 136, 2), 2.0),   # band passes at narrow kernels, 1 / 2 / 4 channels   # line kernels / banded Toeplitz passes (>= 100 taps), ragged blocks
 ])
 def test_blur_matches_oracle(shape, std):
     rng = np.random.default_rng(0)
