@@ -63,6 +63,20 @@ def cpu_baseline(arch, sample_batch, seconds_budget=25.0):
                       f"autograd double backward for the penalty)"}
 
 
+def hbm_traffic(kernel, arch, batch):
+    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py over this very
+    command, separate --pmc runs as MI355X_MICROARCH.md prescribes); None when no profile exists for the workload."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_k_hbm_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+    except OSError:
+        return None
+    if d.get("arch") != arch or d.get("batch") != batch or kernel not in d.get("kernels", {}):
+        return None
+    return round(d["kernels"][kernel]["hbm_bytes_per_launch"])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -130,12 +144,15 @@ def main():
         mfma = {n: k for n, k in kern.items() if n.startswith("conv_") and n != "conv_wgrad_direct"}
         if mfma:
             dom = max(mfma, key=lambda n: mfma[n][1])
-            cnt, ms, fl, _ = mfma[dom]
+            cnt, ms, fl, by = mfma[dom]
             ach = fl / (ms * 1e-3) / 1e12
+            traffic = hbm_traffic(dom, args.arch, B)
             all_ms = sum(k[1] for k in mfma.values())
             all_fl = sum(k[2] for k in mfma.values())
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": None,
+                    "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
+                    "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_k_hbm_traffic.json)" if traffic else None,
+                    "algorithmic_bytes_per_launch": round(by / cnt) if by else None,
                     "launches_per_step": cnt // nprof, "avg_launch_ms": round(ms / cnt, 5),
                     "all_mfma_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 3),
                                          "frac": round(all_fl / (all_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),

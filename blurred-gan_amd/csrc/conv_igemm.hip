@@ -707,6 +707,18 @@ int max_phase_m(const GatherParams& p) {
   return mx;
 }
 
+// algorithmic bytes of one launch: source tensor and the used weight taps read once, result written once
+double gather_bytes(const GatherParams& p) {
+  bool used[bg::kMaxTaps] = {false};
+  int nw = 0;
+  for (int i = 0; i < p.nphase; ++i)
+    for (int t = 0; t < p.ph[i].ntaps; ++t) {
+      const int wi = bg::tap_wi(p.ph[i].tap[t]);
+      if (wi < bg::kMaxTaps && !used[wi]) { used[wi] = true; ++nw; }
+    }
+  return 4.0 * ((double)p.B * p.Hs * p.Ws * p.Ck + (double)nw * p.N * p.Ck + (double)p.B * p.Hd * p.Wd * p.N);
+}
+
 double gather_flops(const GatherParams& p) {
   double f = 0;
   for (int i = 0; i < p.nphase; ++i) f += 2.0 * p.B * p.ph[i].Ha * p.ph[i].Wa * (double)p.N * p.Ck * p.ph[i].ntaps;
@@ -789,7 +801,7 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
   }
   dim3 grid(p.mtiles * bg::cdiv(p.N, BN), 1, (p.nphase / p.pmerge) * ks);
   {
-    bg::Launch L(stream, name, gather_flops(p), 0);
+    bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
     int rc = L.done(name);
     if (rc || ks == 1) return rc;
@@ -871,7 +883,7 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
         attr_tn = true;
       }
       snprintf(name, sizeof name, "conv_thin_n_mfma_%s", tag);
-      bg::Launch L(stream, name, gather_flops(p), 0);
+      bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
       hipLaunchKernelGGL(conv_thin_n_mfma_kernel, dim3(bg::cdiv(p.Wd, kTnCols), bg::cdiv(p.Hd, kTnRows), p.B), dim3(256), lds, L.s, p, k, pt, pl);
       return L.done(name);
     }
@@ -901,7 +913,7 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
       }
       snprintf(name, sizeof name, "conv_thin_n_patch_%s", tag);
       dim3 grid(tiles_x, tiles_y, p.B * p.nphase);
-      bg::Launch L(stream, name, gather_flops(p), 0);
+      bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
       if (p.Ck == 16) hipLaunchKernelGGL(conv_thin_n_patch_kernel<16>, grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);
       else if (p.Ck == 32) hipLaunchKernelGGL(conv_thin_n_patch_kernel<32>, grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);
       else hipLaunchKernelGGL(conv_thin_n_patch_kernel<64>, grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);
@@ -910,7 +922,7 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
   }
   if (p.N <= 4 && p.Ck % 4 == 0) {
     snprintf(name, sizeof name, "conv_thin_n_%s", tag);
-    bg::Launch L(stream, name, gather_flops(p), 0);
+    bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
     hipLaunchKernelGGL(conv_thin_n_kernel, dim3(bg::cdiv(Mmax, 256), 1, p.nphase), dim3(256), 0, L.s, p);
     return L.done(name);
   }
@@ -933,7 +945,7 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     if (kfmax + 1 <= kTkMaxKF && lds <= 60 * 1024) {
       snprintf(name, sizeof name, "conv_thin_k_mfma_%s", tag);
       dim3 grid(tiles_x, tiles_y, p.B * p.nphase);
-      bg::Launch L(stream, name, gather_flops(p), 0);
+      bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
       if (NT == 1) hipLaunchKernelGGL(conv_thin_k_mfma_kernel<1>, grid, dim3(256), lds, L.s, p);
       else hipLaunchKernelGGL(conv_thin_k_mfma_kernel<2>, grid, dim3(256), lds, L.s, p);
       return L.done(name);
@@ -941,12 +953,12 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
   }
   if (p.Ck <= 4) {
     snprintf(name, sizeof name, "conv_thin_k_%s", tag);
-    bg::Launch L(stream, name, gather_flops(p), 0);
+    bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
     hipLaunchKernelGGL(conv_thin_k_kernel, dim3(bg::cdiv(Mmax, 256), bg::cdiv(p.N, 32), p.nphase), dim3(256), 0, L.s, p);
     return L.done(name);
   }
   snprintf(name, sizeof name, "conv_direct_%s", tag);
-  bg::Launch L(stream, name, gather_flops(p), 0);
+  bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
   hipLaunchKernelGGL(conv_direct_kernel, dim3(bg::cdiv((size_t)Mmax * p.N, 256), 1, p.nphase), dim3(256), 0, L.s, p);
   return L.done(name);
 }
