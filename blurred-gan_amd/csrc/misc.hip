@@ -376,15 +376,29 @@ __global__ __launch_bounds__(kT) void lerp_kernel(const float* __restrict__ r, c
   }
 }
 
-__global__ __launch_bounds__(kT) void row_norm_kernel(const float* __restrict__ g, float* __restrict__ norm, int n_per) {
-  __shared__ float red[kT / 64];
+// one workgroup of 1024 threads per sample (B is 128-256: few workgroups, so each must keep many loads in flight); fixed
+// summation order: per-thread strided partials, wave shuffles, then the 16 wave sums in order
+__global__ __launch_bounds__(1024) void row_norm_kernel(const float* __restrict__ g, float* __restrict__ norm, int n_per) {
+  __shared__ float red[16];
   const float* row = g + (size_t)blockIdx.x * n_per;
   float acc = 0.f;
-  for (int i = threadIdx.x; i < n_per; i += kT) acc = fmaf(row[i], row[i], acc);
+  if ((n_per & 3) == 0 && ((reinterpret_cast<uintptr_t>(row) & 15u) == 0)) {
+    const float4* r4 = reinterpret_cast<const float4*>(row);
+    for (int i = threadIdx.x; i < n_per / 4; i += 1024) {
+      const float4 v = r4[i];
+      acc = fmaf(v.x, v.x, acc); acc = fmaf(v.y, v.y, acc); acc = fmaf(v.z, v.z, acc); acc = fmaf(v.w, v.w, acc);
+    }
+  } else {
+    for (int i = threadIdx.x; i < n_per; i += 1024) acc = fmaf(row[i], row[i], acc);
+  }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) norm[blockIdx.x] = sqrtf(red[0] + red[1] + red[2] + red[3]);
+  if (threadIdx.x == 0) {
+    float s = 0.f;
+    for (int w = 0; w < 16; ++w) s += red[w];
+    norm[blockIdx.x] = sqrtf(s);
+  }
 }
 
 __global__ __launch_bounds__(kT) void gp_seed_kernel(const float* __restrict__ g, const float* __restrict__ norm, float coef,
@@ -784,7 +798,7 @@ int bg_lerp_f32(const float* r, const float* f, const float* alpha_b, float* xha
 int bg_row_norm_f32(const float* g, float* norm_b, int B, int n_per, void* stream) {
   BG_POINTWISE_PROLOGUE("bg_row_norm_f32", g && norm_b, (long)B * n_per);
   bg::Launch L(stream, "row_norm", 0, 4.0 * B * n_per);
-  hipLaunchKernelGGL(row_norm_kernel, dim3(B), dim3(kT), 0, L.s, g, norm_b, n_per);
+  hipLaunchKernelGGL(row_norm_kernel, dim3(B), dim3(1024), 0, L.s, g, norm_b, n_per);
   return L.done("row_norm_kernel");
 }
 
