@@ -69,6 +69,34 @@ def test_blur_properties_full_size():
     assert abs(ones[0, 0, 0, 1].item() - g[nt // 2:].sum() ** 2) < 1e-5  # corner darkened by the truncated sums
 
 
+@pytest.mark.parametrize("shape,std", [((128, 128, 128, 3), 5.0), ((64, 256, 256, 3), 5.0), ((64, 256, 256, 3), 23.5), ((64, 256, 256, 3), 42.34)])
+def test_blur_properties_c4_c5_sizes(shape, std):
+    """The same size-independent properties at BASELINE.json's C4 (128x128, batch 128) and C5 (256x256, 64 per GPU; 31 / 143 / 255
+    taps) sizes, which run the two transposing band passes through the scratch image."""
+    from blurred_gan_amd import ops
+    torch.manual_seed(1)
+    B, H, W, C = shape
+    ks, se, nt = ops.blur_policy(std, H, W)
+    taps = torch.tensor(ops.gauss_kernel_1d(se, ks), device="cuda")
+    tmp = torch.empty(shape, device="cuda")
+    assert ops.blur_workspace_bytes(B, H, W, C, nt) == tmp.numel() * 4
+    x = torch.rand(shape, device="cuda") * 2 - 1
+    y = torch.rand(shape, device="cuda") * 2 - 1
+    bl = lambda t: ops.blur_nhwc(t.contiguous(), torch.empty_like(t), taps, nt, tmp)
+    bx, by = bl(x), bl(y)
+    lhs, rhs = (bx.double() * y.double()).sum().item(), (x.double() * by.double()).sum().item()
+    assert abs(lhs - rhs) < 1e-5 * max(1.0, abs(lhs))
+    z = bl(2.0 * x + 3.0 * y)
+    assert (z - (2.0 * bx + 3.0 * by)).abs().max().item() < 2e-5
+    ones = bl(torch.ones(shape, device="cuda"))
+    g = np.array(ops.gauss_kernel_1d(se, ks), np.float64)
+    half = nt // 2
+    inner = g[max(0, half - H // 2):half + (H - H // 2)].sum() ** 2              # taps that stay inside the image from its centre
+    assert abs(ones[0, H // 2, W // 2, 0].item() - inner) < 2e-5
+    assert abs(ones[B - 1, 0, 0, C - 1].item() - g[half:].sum() ** 2) < 2e-5
+    assert torch.equal(ones[0], ones[B - 1])                                      # every image of the batch alike
+
+
 def test_blur_rejects_bad_arguments():
     from blurred_gan_amd import ops
     x = torch.zeros(1, 4, 4, 3, device="cuda")
