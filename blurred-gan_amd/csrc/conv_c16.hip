@@ -303,6 +303,20 @@ void fill_epilogue(C16Params& p, const bg_epilogue* epi) {
   }
 }
 
+// argument checks of the fused epilogues (only for shapes these kernels take)
+int check_epilogue(const bg_epilogue* epi) {
+  if (epi) {
+    BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "conv c16: epilogue mode %d", epi->mode);
+    BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || epi->ref, BG_ERR_NULL, "conv c16: BG_EPI_MUL_GRAD needs ref");
+    BG_REQUIRE(epi->mode != BG_EPI_AFFINE_LRELU || (epi->ref && epi->bias), BG_ERR_NULL, "conv c16: BG_EPI_AFFINE_LRELU needs ref and bias");
+    // the epilogues work on 4 consecutive channels of a pixel: float4 loads of ref, uchar4 loads of the mask
+    BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || bg::aligned16(epi->ref), BG_ERR_BAD_ALIGNMENT, "conv c16: ref must be 16-byte aligned");
+    BG_REQUIRE(!epi->keep || ((reinterpret_cast<uintptr_t>(epi->keep) & 3u) == 0 && epi->keep_elems % 4 == 0), BG_ERR_BAD_ALIGNMENT,
+               "conv c16: keep mask must be 4-byte aligned and keep_elems a multiple of 4");
+  }
+  return BG_OK;
+}
+
 }  // namespace
 
 namespace bg {
@@ -313,16 +327,12 @@ int try_conv_c16(int bwd_data, const float* a, const float* w, float* c, int B, 
   *taken = 0;
   static const int off = getenv("BG_NO_C16") ? 1 : 0;
   if (off || k != 5 || s != 2 || (H & 1) || (W & 1)) return BG_OK;
-  if (epi) {
-    BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "conv c16: epilogue mode %d", epi->mode);
-    BG_REQUIRE(epi->mode != BG_EPI_MUL_GRAD || epi->ref, BG_ERR_NULL, "conv c16: BG_EPI_MUL_GRAD needs ref");
-    BG_REQUIRE(epi->mode != BG_EPI_AFFINE_LRELU || (epi->ref && epi->bias), BG_ERR_NULL, "conv c16: BG_EPI_AFFINE_LRELU needs ref and bias");
-  }
   C16Params p;
   memset(&p, 0, sizeof p);
   if (bwd_data) {      // dy [B,H/2,W/2,Cout] -> dx [B,H,W,Cin = 16]
     const int Hs = H / 2, Ws = W / 2;
     if (Cin != 16 || Cout != kDgCk || (Ws != 32 && Ws != 64) || (Hs & 1)) return BG_OK;
+    if (int rc = check_epilogue(epi)) return rc;
     if ((size_t)B * H * W * 16 >= (1ull << 29) || (size_t)B * Hs * Ws * Cout >= (1ull << 29)) return BG_OK;
     p.A = a; p.Wt = w; p.C = c;
     p.B = B; p.Hs = Hs; p.Ws = Ws; p.Ck = Cout; p.Hd = H; p.Wd = W; p.N = 16;
@@ -350,6 +360,7 @@ int try_conv_c16(int bwd_data, const float* a, const float* w, float* c, int B, 
   {
     const int Ho = H / 2, Wo = W / 2;
     if (Cin != 16 || Cout != 32 || (Wo != 32 && Wo != 64) || (Ho & 1)) return BG_OK;
+    if (int rc = check_epilogue(epi)) return rc;
     if ((size_t)B * H * W * 16 >= (1ull << 29) || (size_t)B * Ho * Wo * 32 >= (1ull << 29)) return BG_OK;
     p.A = a; p.Wt = w; p.C = c;
     p.B = B; p.Hs = H; p.Ws = W; p.Ck = 16; p.Hd = Ho; p.Wd = Wo; p.N = 32;
