@@ -216,3 +216,40 @@ def test_conv_rejects_bad_arguments():
         ops.conv2d_fwd(x, torch.zeros(49 * 32 * 32, device="cuda"), torch.zeros(1, 4, 4, 32, device="cuda"), 7, 1)   # k*k > 25
     with pytest.raises(ValueError):
         ops.conv2d_fwd(x, w, torch.zeros(1, 2, 2, 32, device="cuda"), 3, 3)                                          # stride 3
+
+
+def _random_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    chans = [1, 2, 3, 4, 8, 12, 16, 20, 32, 48, 64, 96, 128]
+    out = []
+    while len(out) < n:
+        B = int(rng.integers(1, 6))
+        H, W = int(rng.integers(2, 41)), int(rng.integers(2, 41))
+        if rng.uniform() < 0.3:                                   # the row kernels want widths that are multiples of 16
+            W = int(rng.choice([16, 32, 64]))
+        Ci, Co = int(rng.choice(chans)), int(rng.choice(chans))
+        s = int(rng.choice([1, 2]))
+        if B * H * W * max(Ci, Co) > 400_000:
+            continue
+        out.append((B, H, W, Ci, Co, s))
+    return out
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,s", _random_cases(48, 20261004))
+def test_conv_random_shapes(B, H, W, Ci, Co, s):
+    """Seeded random geometries across the dispatch boundaries (thin / 16-channel / MFMA / direct paths, odd sizes, both strides):
+    forward, data gradient and filter gradient against the float64 oracle."""
+    from blurred_gan_amd import ops
+    x, w, dy = _data(B, H, W, Ci, Co, s, seed=B * 1000 + H * 31 + W)
+    wT = dev(np.transpose(w, (0, 1, 3, 2)))
+    ref = O.conv2d_fwd(x, w, s)
+    y = ops.conv2d_fwd(dev(x), wT, torch.empty(ref.shape, device="cuda"), 5, s)
+    np.testing.assert_allclose(y.cpu().numpy(), ref, rtol=1e-4, atol=conv_tol(25 * Ci, np.abs(ref).max()))
+    refd = O.conv2d_bwd_data(dy, w, s, (H, W))
+    dx = ops.conv2d_bwd_data(dev(dy), dev(w), torch.empty(x.shape, device="cuda"), 5, s)
+    np.testing.assert_allclose(dx.cpu().numpy(), refd, rtol=1e-4, atol=conv_tol(25 * Co, np.abs(refd).max()))
+    refw = O.conv2d_bwd_filter(x, dy, s, 5)
+    nb = ops.conv2d_bwd_filter_workspace_bytes(B, H, W, Ci, Co, 5, s)
+    ws = torch.empty(nb // 4 + 4, device="cuda") if nb else None
+    dw = ops.conv2d_bwd_filter(dev(x), dev(dy), torch.empty(w.shape, device="cuda"), 5, s, 0.0, 1.0, ws)
+    np.testing.assert_allclose(dw.cpu().numpy(), refw, rtol=1e-4, atol=conv_tol(dy[..., 0].size, np.abs(refw).max()))
