@@ -38,6 +38,27 @@ def test_blur_matches_oracle(shape, std):
     np.testing.assert_allclose(y, ref, rtol=POINT_RTOL, atol=POINT_ATOL * 4)
 
 
+def _random_blur_cases(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        B, H, W = int(rng.integers(1, 4)), int(rng.integers(3, 200)), int(rng.integers(3, 200))
+        C = int(rng.choice([1, 2, 3, 4, 5, 8]))
+        if B * H * W * C > 300_000:
+            continue
+        out.append(((B, H, W, C), float(rng.choice([0.05, 0.4, 0.9, 1.7, 3.0, 5.0, 9.0, 15.0, 23.5, 40.0]))))
+    return out
+
+
+@pytest.mark.parametrize("shape,std", _random_blur_cases(32, 4242))
+def test_blur_random_shapes(shape, std):
+    """Seeded random image sizes, channel counts and sigmas across the kernel-family boundaries (whole-image MFMA / sliding
+    window, band passes, line kernels for more than 4 channels)."""
+    x = np.random.default_rng(7).uniform(-1, 1, size=shape).astype(np.float32)
+    y, _ = _run(x, std)
+    np.testing.assert_allclose(y, O.blur_images(x.astype(np.float64), std), rtol=POINT_RTOL, atol=POINT_ATOL * 4)
+
+
 def test_gauss_kernel_host_matches_oracle():
     from blurred_gan_amd import ops
     for std, hw in [(0.05, 28), (1.0, 64), (5.0, 64), (4.94, 64), (23.5, 256), (42.34, 256)]:
