@@ -80,8 +80,8 @@ def hbm_traffic(kernel, arch, batch):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--arch", default="celeba64", choices=["celeba64", "celeba128", "mnist"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256; 128 for celeba128; 64 for mnist)")
     ap.add_argument("--sigma", type=float, default=5.0)
