@@ -91,6 +91,18 @@ def main():
     ap.add_argument("--kernels-out", default=None, help="write the full per-kernel table (and one step's launch sequence) to this JSON file")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "RANK" not in os.environ:
+        # started bare with --gpus N: become the launcher (one rank per GPU over RCCL) -- as a child process, before anything
+        # here has touched the GPU
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+        sys.exit(subprocess.run(cmd).returncode)
+
     from blurred_gan_amd import dist, ops, callbacks
     world = dist.init_from_env()
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
