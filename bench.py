@@ -34,7 +34,7 @@ def build_gan(arch, B, world, sigma):
     bg.set_seed(123123)                                   # demo_celeba.py:132; every rank starts from identical weights
     gen, disc = models.DCGANGenerator(arch=arch), models.DCGANDiscriminator(arch=arch)
     hp = bg.BlurredWGANGP.HyperParameters(initial_blur_std=sigma, batch_size=B, global_batch_size=B * world)
-    gan = bg.BlurredWGANGP(gen, disc, hp, bg.TrainingConfig(log_dir="/tmp/bg_bench_logs"), sync_metrics=False)
+    gan = bg.BlurredWGANGP(gen, disc, hp, bg.TrainingConfig(log_dir="/tmp/bg_bench_logs"))
     gan._rng_seed = 123123 + dist.rank()
     return gan
 

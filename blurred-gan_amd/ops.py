@@ -13,26 +13,38 @@ from ._lib import Epilogue, EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EP
 LRELU_ALPHA = 0.3
 
 
-_dev_index = None
+_dev_index = None          # device the last launch's tensors were verified against (refreshed whenever a tensor disagrees)
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_get_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
 def _stream():
-    """Raw handle of torch's CURRENT stream on this process's device (one process per GPU).  The raw-stream query is a
-    single C call; ``torch.cuda.current_stream()`` builds a Python object per call and was a third of the host time of a step."""
-    global _dev_index
-    if _raw_stream is None:
+    """Raw handle of torch's CURRENT stream on the CURRENT device (one process per GPU; `_ptr` has checked that every
+    operand lives there).  The raw-stream query is a single C call; ``torch.cuda.current_stream()`` builds a Python object
+    per call and was a third of the host time of a step."""
+    if _raw_stream is None or _get_device is None:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    if _dev_index is None:
-        _dev_index = torch.cuda.current_device()
-    return C.c_void_p(_raw_stream(_dev_index))
+    cur = _get_device()
+    if _dev_index is not None and cur != _dev_index:
+        raise BgDeviceError(f"operands live on cuda:{_dev_index} but the current device is cuda:{cur}")
+    return C.c_void_p(_raw_stream(cur))
 
 
 def _ptr(t):
+    """Raw device address of a contiguous tensor that lives on the process's current device.  A CPU tensor or a tensor of
+    another GPU raises: the kernels are launched on the current device's stream and must never see foreign pointers."""
+    global _dev_index
     if t is None:
         return None
-    if not t.is_cuda:
-        raise BgDeviceError("tensor must live on the GPU (cuda/ROCm device); the HIP path has no CPU fallback")
+    d = t.get_device()
+    if d != _dev_index:
+        if d < 0:
+            raise BgDeviceError("tensor must live on the GPU (cuda/ROCm device); the HIP path has no CPU fallback")
+        cur = torch.cuda.current_device()
+        if d != cur:
+            raise BgDeviceError(f"tensor lives on cuda:{d} but the current device is cuda:{cur}: call "
+                                "torch.cuda.set_device(local_rank) before building the model (one process per GPU)")
+        _dev_index = cur
     if not t.is_contiguous():
         raise ValueError("tensor must be contiguous")
     return C.c_void_p(t.data_ptr())

@@ -128,7 +128,14 @@ class WGAN:
         self.images = None
         # --- build-side switches (documented in DESIGN.md)
         self.reproduce_vector_loss_quirk = reproduce_vector_loss_quirk
-        self.sync_metrics = sync_metrics     # False: skip the per-step device->host metric read (bench)
+        # Metrics live in one 16-float device buffer (critic step [0:8], generator step [8:12]).  train_on_batch reads it ONCE,
+        # after the last kernel of the step has been enqueued (asynchronous copy into pinned memory + event wait): the one
+        # host<->device synchronisation of a step, where Keras' train_on_batch converts its metric tensors (wgan.py:114).
+        # sync_metrics=False skips even that (the returned metrics are then zeros): a measuring aid, never used by bench.py.
+        self.sync_metrics = sync_metrics
+        self._defer_metrics = False
+        self._met_host = None
+        self._met_event = None
         self.sync_batchnorm = sync_batchnorm  # DP: generator BN statistics over the global batch (False = per replica)
         # critic step: [fakes; reals] and x-hat in one 3B-sample forward / backward (False: two passes, as the reference orders them)
         self.merge_critic_passes = merge_critic_passes and not os.environ.get("BGAN_NO_MERGED_CRITIC")
@@ -188,16 +195,50 @@ class WGAN:
         reals = self._as_device(reals)
         self.batch_size = int(reals.shape[0])
         self._injected = randomness
+        self._defer_metrics = True
         try:
             disc_loss, self.images = self.discriminator_step(reals)
-            if int(self.n_batches) % self.d_steps_per_g_step == 0:
+            g_ran = int(self.n_batches) % self.d_steps_per_g_step == 0
+            if g_ran:
                 self.generator_step()
         finally:
             self._injected = None
+            self._defer_metrics = False
+        if self.sync_metrics:
+            m = self._read_metrics()
+            self._record_d_metrics(m[:8])
+            if g_ran:
+                self._record_g_metrics(m[8:12])
         self.log_image_summaries()
         self.n_img.assign_add(self.batch_size)
         self.n_batches.assign_add(1)
         return self._organize_metrics()
+
+    def _metrics_dev(self):
+        return self._buf("step_metrics", (16,))
+
+    def _read_metrics(self):
+        """ONE device->host read of the step's metric buffer: asynchronous copy into pinned memory behind everything enqueued
+        so far, then wait for that copy only."""
+        dev = self._metrics_dev()
+        if self._met_host is None:
+            self._met_host = torch.empty(16, dtype=torch.float32, pin_memory=dev.is_cuda)
+            self._met_event = torch.cuda.Event() if dev.is_cuda else None
+        self._met_host.copy_(dev, non_blocking=True)
+        if self._met_event is not None:
+            self._met_event.record()
+            self._met_event.synchronize()
+        return self._met_host.tolist()
+
+    def _record_d_metrics(self, m):
+        self.fake_scores_metric(m[0])
+        self.real_scores_metric(m[1])
+        self.disc_loss_metric(m[2])
+        self._record_gp_metrics(m)
+
+    def _record_g_metrics(self, m):
+        self.fake_scores_metric(m[0])                      # Q6: second update of the same Mean
+        self.gen_loss_metric(m[1])
 
     def _as_device(self, x):
         if isinstance(x, np.ndarray):
@@ -240,7 +281,7 @@ class WGAN:
         inv_gbs = 1.0 / float(hp.global_batch_size)
         gp_c = float(getattr(hp, "gp_coefficient", 0.0)) if self.uses_gradient_penalty else 0.0
         e_d = float(getattr(hp, "e_drift", 0.0)) if self.uses_gradient_penalty else 0.0
-        met = self._buf("d_metrics", (8,))
+        met = self._metrics_dev()[:8]
         vs = self._vec_scale(B)
         store = self.discriminator.store
         store.ensure_opt_state()
@@ -290,16 +331,11 @@ class WGAN:
                 D.gp_second_order(chat, v0, reducer=red)
         red.finish()
         self.discriminator.optimizer.apply(store)
-        self._d_metrics_dev = met
-        if self.sync_metrics:
-            m = met.cpu().tolist()
-            self.fake_scores_metric(m[0])
-            self.real_scores_metric(m[1])
-            self.disc_loss_metric(m[2])
-            self._record_gp_metrics(m)
+        disc_loss = None              # inside train_on_batch the value is read with the rest of the step's metrics
+        if self.sync_metrics and not self._defer_metrics:
+            m = self._read_metrics()
+            self._record_d_metrics(m[:8])
             disc_loss = m[2]
-        else:
-            disc_loss = None
         return disc_loss, (fakes, reals)
 
     def _record_gp_metrics(self, m):
@@ -343,7 +379,7 @@ class WGAN:
         chat = D.context(B, "hat")
         s = D.forward(chat, fakes, training=False).view(B)
         ds = self._buf("ds_g", (B,))
-        met = self._buf("g_metrics", (4,))
+        met = self._metrics_dev()[8:12]
         ops.wgan_g_loss(s, 1.0 / float(self.hparams.global_batch_size), ds, met)
         dfakes = D.backward(chat, ds.view(B, 1), need_dx=True, need_dw=False)
         store = self.generator.store
@@ -352,12 +388,10 @@ class WGAN:
         G.backward(cg, dfakes, need_dx=False, need_dw=True, beta=0.0, scale=1.0, reducer=red)
         red.finish()
         self.generator.optimizer.apply(store)
-        self._g_metrics_dev = met
-        if self.sync_metrics:
-            m = met.cpu().tolist()
-            self.fake_scores_metric(m[0])                      # Q6: second update of the same Mean
-            self.gen_loss_metric(m[1])
-            return m[1]
+        if self.sync_metrics and not self._defer_metrics:
+            m = self._read_metrics()
+            self._record_g_metrics(m[8:12])
+            return m[1 + 8]
         return None
 
     # ---- bookkeeping / Keras surface

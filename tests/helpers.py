@@ -47,3 +47,29 @@ def oracle_grad_list(grads):
 
 def dev(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
+
+
+def product_slots(model, which):
+    """Adam slot ('m' or 'v') arrays in trainable-variable order."""
+    st = model.store
+    own = {id(l) for l in model._own_layers()}
+    buf = getattr(st, which)
+    return [st.view_like(buf, l, n).detach().cpu().numpy().copy() for (l, n, _, _, tr) in st.entries if tr and id(l) in own]
+
+
+def sync_oracle_from_product(st, gan):
+    """Overwrites the oracle state's weights, BN statistics and Adam slots with the PRODUCT's current values (float64
+    copies of its float32 buffers), so that the next oracle step starts from exactly the state the product is in."""
+    for model, key in ((gan.generator, "g"), (gan.discriminator, "d")):
+        it = iter(model.get_weights())
+        for p in st[key]:
+            for k in ("kernel", "bias", "gamma", "beta", "moving_mean", "moving_var"):
+                if k in p:
+                    p[k] = next(it).astype(np.float64).reshape(p[k].shape)
+        for slot in ("m", "v"):
+            it = iter(product_slots(model, slot))
+            for p in st[f"{key}_{slot}"]:
+                for k in ("kernel", "bias", "gamma", "beta"):
+                    if k in p:
+                        p[k] = next(it).astype(np.float64).reshape(p[k].shape)
+    return st

@@ -127,7 +127,10 @@ def test_checkpoint_manager_round_trip_and_rotation(tmp_path):
     gan.generator.trainable_variables[0].fill_(1.5)
     for n in (100, 200, 300):
         mgr.save(n)
-    assert [p.split("-")[-1] for p in mgr._paths()] == ["200.npz", "300.npz"]          # max_to_keep
+    assert [p.split("-")[-1] for p in mgr.checkpoints] == ["200.npz", "300.npz"]          # max_to_keep
+    gan._rng_off = 1234
+    gan.discriminator.net().rng_offset = 77
+    mgr.save(300)
     other = make()
     CheckpointManager(other, str(tmp_path / "ckpt")).restore(mgr.latest_checkpoint)
     assert int(other.n_img) == 640 and int(other.n_batches) == 20 and abs(float(other.std) - 0.75) < 1e-7
@@ -135,6 +138,34 @@ def test_checkpoint_manager_round_trip_and_rotation(tmp_path):
     assert torch.equal(other.generator.store.theta, gan.generator.store.theta)
     assert torch.equal(other.generator.store.m, gan.generator.store.m)
     assert torch.equal(other.discriminator.store.state, gan.discriminator.store.state)
+    assert other._rng_off == 1234 and other.discriminator.net().rng_offset == 77      # random streams continue, not replay
+
+
+def test_checkpoint_manager_orders_by_save_time_not_by_file_number(tmp_path):
+    """tf.train.CheckpointManager semantics: SaveModelCallback numbers files with a counter that restarts at every fit()
+    (callbacks.py:245), so after a resume the NEW files carry SMALLER numbers; they must still be the latest and the
+    ones kept (save -> restore -> fit -> save)."""
+    from blurred_gan_amd.checkpoint import CheckpointManager
+    bg.set_seed(5)
+    g, d = models.DCGANGenerator(arch="tiny"), models.DCGANDiscriminator(arch="tiny")
+    gan = bg.BlurredWGANGP(g, d, bg.BlurredWGANGP.HyperParameters(), bg.TrainingConfig())
+    mgr = CheckpointManager(gan, str(tmp_path / "c"), max_to_keep=2)
+    gan.n_img.assign(100000)
+    mgr.save(100000)
+    mgr2 = CheckpointManager(gan, str(tmp_path / "c"), max_to_keep=2)      # the resumed process
+    mgr2.restore(mgr2.latest_checkpoint)
+    gan.n_img.assign(100032)
+    mgr2.save(32)
+    assert mgr2.latest_checkpoint.endswith("ckpt-32.npz")
+    gan.n_img.assign(110016)
+    mgr2.save(10016)
+    assert [os.path.basename(p) for p in mgr2.checkpoints] == ["ckpt-32.npz", "ckpt-10016.npz"]
+    assert not os.path.exists(tmp_path / "c" / "ckpt-100000.npz")
+    assert not [n for n in os.listdir(tmp_path / "c") if "tmp" in n]       # atomic writes leave no partial files
+    keep_all = CheckpointManager(gan, str(tmp_path / "k"), max_to_keep=None)
+    for n in range(7):
+        keep_all.save(n)
+    assert len(keep_all.checkpoints) == 7
 
 
 def test_feed_images_to_metric_callback_counts():

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import step as S
-from helpers import load_oracle_weights, product_grads, oracle_grad_list, oracle_weight_list
+from helpers import load_oracle_weights, product_grads, product_slots, oracle_grad_list, oracle_weight_list
 
 pytestmark = pytest.mark.gpu
 
@@ -88,6 +88,81 @@ def test_three_training_steps_match_oracle(arch, B, std):
             np.testing.assert_allclose(a, b.reshape(a.shape), rtol=1e-3, atol=2e-4)
 
 
+@pytest.mark.parametrize("arch,B,std,steps", [("celeba64", 8, 5.0, 3), ("mnist", 8, 0.05, 3), ("celeba128", 4, 5.0, 2)])
+def test_real_architecture_training_steps_match_oracle(arch, B, std, steps):
+    """Consecutive full steps with the REAL learning rate at the real layer shapes (wgan.py:140-141,166-167): after every
+    train_on_batch the weights, both Adam slots, the BatchNorm moving statistics, the optimiser iteration counts and the
+    counters of the HIP path equal the float64 oracle's.  The product runs its steps back to back, untouched: that is what
+    exercises the flat-buffer Adam (bias correction at t = 1, 2, 3), the refresh of the transposed weight copies the forward
+    kernels read, and the G-step's moving-statistics update at 16 M parameters.
+
+    Why the oracle is re-synchronised to the product's state before each step: a free-running comparison is ill-conditioned,
+    not informative.  Adam's first updates are lr * g / (|g| + 1e-7), so a weight whose gradient is within float32 noise of
+    zero steps +lr in one implementation and -lr in the other, and BatchNorm at a small batch amplifies that: the ORACLE
+    ITSELF run in float32 is 7e-2 (step 2) and 0.27 (step 3) of the maximum away from its float64 run on the generator's first
+    moments at celeba64 / batch 8.  Compared step by step from a common state the slots agree to ~5e-4."""
+    from helpers import sync_oracle_from_product
+    gan, st, reals, rng = _make(arch, B, std, seed=5)
+    hp = dict(S.DEFAULT_HP, global_batch_size=B)
+    lr = hp["learning_rate"]
+    worst = {}
+    for it in range(steps):
+        if it:
+            sync_oracle_from_product(st, gan)               # the product itself is NOT reloaded
+        rnd = S.draw_randomness(arch, B, rng, np.float64)
+        r = rng.uniform(-1, 1, size=reals.shape)
+        st, met, _ = S.train_on_batch(st, r, rnd, hp)
+        got = dict(zip(gan.metrics_names, gan.train_on_batch(r.astype(np.float32), randomness=rnd)))
+        for k in ("disc_loss", "gen_loss", "gp_term", "real_scores", "fake_scores"):
+            assert abs(got[k] - met[k]) < 1e-3 * (abs(met[k]) + 0.1), (it, k, got[k], met[k])
+        assert int(gan.n_img) == (it + 1) * B == st["n_img"] and int(gan.n_batches) == it + 1 == st["n_batches"]
+        assert gan.generator.optimizer.iterations == st["g_t"] == it + 1
+        assert gan.discriminator.optimizer.iterations == st["d_t"] == it + 1
+        for model, key in ((gan.generator, "g"), (gan.discriminator, "d")):
+            names = [n for (l, n, _, _, tr) in model.store.entries if id(l) in {id(x) for x in model._own_layers()}]
+            for a, b, name in zip(model.get_weights(), oracle_weight_list(st[key]), names):     # weights AND BN moving statistics
+                b = b.reshape(a.shape)
+                err = np.abs(a - b)
+                if name.startswith("moving"):
+                    np.testing.assert_allclose(a, b, rtol=2e-4, atol=2e-6, err_msg=f"{key} {name} step {it}")
+                    continue
+                # one Adam step moves a weight by at most ~lr; where the gradient is float32 noise the SIGN of that move is too
+                assert err.max() <= 2.0 * lr + 1e-6, (key, name, a.shape, err.max())
+                bad = float((err > 1e-3 * np.abs(b) + 1e-4).mean())
+                worst[key + "_w_bad_frac"] = max(worst.get(key + "_w_bad_frac", 0.0), bad)
+                assert bad <= 0.02, (key, name, a.shape, bad)
+            for slot in ("m", "v"):
+                for a, b in zip(product_slots(model, slot), oracle_grad_list(st[f"{key}_{slot}"])):
+                    b = np.asarray(b, dtype=np.float64).reshape(a.shape)
+                    e = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+                    worst[key + "_" + slot] = max(worst.get(key + "_" + slot, 0.0), e)
+                    assert e <= (1e-2 if key == "g" else 3e-3), (key, slot, a.shape, e, it)
+    print(f"{arch} B={B} {steps} steps: worst deviations {worst}")
+
+
+def test_celeba64_batch256_step_matches_oracle():
+    """The exact BASELINE.json configuration (64x64, batch 256, sigma 5 -> 31 taps): one full train_on_batch against the
+    float64 numpy oracle on identical injected randomness (learning rate 0 so the gradients can be read back).  The oracle
+    needs ~1 minute of host time at this batch; the generator tolerance follows test_gradients_match_oracle's B >= 64 case."""
+    arch, B, std = "celeba64", 256, 5.0
+    gan, st, reals, rng = _make(arch, B, std, seed=9)
+    rnd = S.draw_randomness(arch, B, rng, np.float64)
+    hp = dict(S.DEFAULT_HP, global_batch_size=B)
+    dg, met, fakes = S.discriminator_grads(st, reals, rnd, hp)
+    gg, upd, gm = S.generator_grads(st, rnd, hp, B)
+    gan.discriminator.optimizer.learning_rate = 0.0
+    gan.generator.optimizer.learning_rate = 0.0
+    got = dict(zip(gan.metrics_names, gan.train_on_batch(reals.astype(np.float32), randomness=rnd)))
+    for a, b in zip(product_grads(gan.discriminator), oracle_grad_list(dg)):
+        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=2e-4 * max(np.abs(b).max(), 1e-6))
+    for a, b in zip(product_grads(gan.generator), oracle_grad_list(gg)):
+        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=1e-2 * max(np.abs(b).max(), 1e-6))
+    np.testing.assert_allclose(gan.images[0].cpu().numpy(), fakes, rtol=1e-4, atol=1e-5)
+    for k in ("real_scores", "disc_loss", "gp_term", "norm_term"):
+        assert abs(got[k] - met[k]) < 1e-4 * max(1, abs(met[k])), (k, got[k], met[k])
+    assert abs(got["gen_loss"] - gm["gen_loss"]) < 1e-4 * max(1, abs(gm["gen_loss"]))
+
+
 def test_vector_loss_quirk_switch():
     """Q1 on/off changes the critic gradient exactly by the documented factor on the W + GP part."""
     arch, B = "tiny", 4
@@ -140,3 +215,37 @@ def test_loss_curves_track_the_oracle_over_25_steps():
             assert err < 1e-2, (it, k, got[k], met[k])
     assert int(gan.n_batches) == 25
     print("worst relative metric deviation over 25 steps:", worst)
+
+
+def test_resume_from_checkpoint_equals_uninterrupted_run(tmp_path):
+    """N2 (demo_mnist.py:145-163,191): 3 steps, save, restore into a NEW model, 3 more steps == 6 uninterrupted steps, bit
+    for bit -- weights, BN statistics, Adam slots, counters, sigma AND the positions of the build's own random streams
+    (latents, alpha, dropout masks), with the step's own RNG (nothing injected)."""
+    import blurred_gan_amd as bg
+    from blurred_gan_amd import models, callbacks
+    from blurred_gan_amd.checkpoint import CheckpointManager
+    arch, B = "mnist", 8
+
+    def make(seed):
+        bg.set_seed(seed)
+        gen, disc = models.DCGANGenerator(arch=arch), models.DCGANDiscriminator(arch=arch)
+        hp = bg.BlurredWGANGP.HyperParameters(initial_blur_std=2.0, global_batch_size=B, batch_size=B)
+        return bg.BlurredWGANGP(gen, disc, hp, bg.TrainingConfig(log_dir=str(tmp_path / "log")))
+    g = torch.Generator().manual_seed(1)
+    data = [torch.rand(B, 28, 28, 1, generator=g) * 2 - 1 for _ in range(6)]
+    ctl = lambda: callbacks.BlurDecayController(total_n_training_examples=100, max_value=2.0)
+    full = make(7)
+    full.fit(data, epochs=1, callbacks=[ctl()])
+    first = make(7)
+    first.fit(data[:3], epochs=1, callbacks=[ctl()])
+    mgr = CheckpointManager(first, str(tmp_path / "ckpt"))
+    mgr.save()
+    resumed = make(99)                                    # different initial weights and seed: everything must come from the file
+    CheckpointManager(resumed, str(tmp_path / "ckpt")).restore(mgr.latest_checkpoint)
+    assert int(resumed.n_batches) == 3 and int(resumed.n_img) == 3 * B
+    resumed.fit(data[3:], epochs=1, callbacks=[ctl()])
+    assert int(resumed.n_batches) == int(full.n_batches) == 6 and float(resumed.std) == float(full.std)
+    for a, b in ((resumed.generator, full.generator), (resumed.discriminator, full.discriminator)):
+        for name in ("theta", "state", "m", "v"):
+            assert torch.equal(getattr(a.store, name), getattr(b.store, name)), name
+        assert a.optimizer.iterations == b.optimizer.iterations == 6
