@@ -39,28 +39,41 @@ def build_gan(arch, B, world, sigma):
     return gan
 
 
-def cpu_baseline(arch, sample_batch, seconds_budget=25.0):
-    """The oracle's torch-CPU port of the same step, timed on this box's host cores (reported, not a target)."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(arch, batch, sigma, seconds_budget=30.0):
+    """The oracle's torch-CPU port of the same step at the SAME batch as the GPU line, timed on this box's host cores
+    (reported, not a target).  One small-batch step warms oneDNN up, then whole steps at the quoted batch are timed until
+    the budget is spent (at ~10 images/s one batch-256 step is the whole sample)."""
     from oracle.torch_ref import TorchTrainer
     from oracle import models as OM
     torch.manual_seed(0)
-    tr = TorchTrainer(arch, seed=0, std=5.0, hp=dict(global_batch_size=sample_batch))
-    gen = torch.Generator().manual_seed(0)
     H, W, C = OM.image_shape(arch)
-    reals = torch.rand(sample_batch, H, W, C, generator=gen) * 2 - 1
-    t0 = time.time()
-    tr.train_on_batch(reals, tr.draw(sample_batch, gen))         # warm-up (oneDNN primitive creation)
-    warm = time.time() - t0
+    gen = torch.Generator().manual_seed(0)
+    warm = TorchTrainer(arch, seed=0, std=sigma, hp=dict(global_batch_size=8))
+    warm.train_on_batch(torch.rand(8, H, W, C, generator=gen) * 2 - 1, warm.draw(8, gen))
+    tr = TorchTrainer(arch, seed=0, std=sigma, hp=dict(global_batch_size=batch))
+    reals = torch.rand(batch, H, W, C, generator=gen) * 2 - 1
     n, t0 = 0, time.time()
     while True:
-        tr.train_on_batch(reals, tr.draw(sample_batch, gen))
+        tr.train_on_batch(reals, tr.draw(batch, gen))
         n += 1
-        if time.time() - t0 + warm > seconds_budget or n >= 5:
+        if time.time() - t0 > seconds_budget or n >= 20:
             break
     dt = time.time() - t0
-    return {"value": round(sample_batch * n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} step(s) of batch {sample_batch} of the same {arch} step (oracle/torch_ref.py, torch-CPU fp32, "
-                      f"autograd double backward for the penalty)"}
+    return {"value": round(batch * n / dt, 3), "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu": cpu_model(), "host_cpus": os.cpu_count(),
+            "sample": f"{n} step(s) of batch {batch} of the same {arch} step in {dt:.1f} s (oracle/torch_ref.py, torch-CPU fp32 on "
+                      f"{torch.get_num_threads()} threads, autograd double backward for the penalty)"}
 
 
 def hbm_traffic(kernel, arch, batch):
@@ -77,19 +90,91 @@ def hbm_traffic(kernel, arch, batch):
     return round(d["kernels"][kernel]["hbm_bytes_per_launch"])
 
 
+def bench_blur(args):
+    """BASELINE.json configs[4] (C5), one rank's share: 64 synthetic 256x256x3 images, a step = the 7 blur applications of one
+    training step (D-step forward x3, blur^T, GP second order; G-step forward, blur^T) at the given sigma
+    (5 -> 31 taps, the bandwidth-bound control; 23.5 -> 143 and 42.34 -> 255 taps, the callback default / the largest
+    reasonable sigma, gaussian_blur.py:15-18).  value = algorithmic GB/s, 8*H*W*C bytes per image per application
+    (SURVEY.md 8d), over the whole timed region; roofline = the same figure over the kernels' own HIP-event durations."""
+    from blurred_gan_amd import dist, ops
+    world = dist.init_from_env()
+    torch.cuda.set_device(dist.local_rank())
+    B, H, W, C = args.batch or 64, 256, 256, 3
+    apps = 7
+    g = torch.Generator(device="cuda").manual_seed(123123 + dist.rank())
+    x = torch.rand(B, H, W, C, device="cuda", generator=g) * 2 - 1
+    y = torch.empty_like(x)
+    ks, se, nt = ops.blur_policy(args.sigma, H, W)
+    taps = torch.tensor(ops.gauss_kernel_1d(se, ks), device="cuda")
+    nb = ops.blur_workspace_bytes(B, H, W, C, nt)
+    tmp = torch.empty(nb // 4 + 4, device="cuda") if nb else None
+
+    def step():
+        for i in range(apps):                  # ping-pong so that no application reads what the cache still holds of its own output
+            ops.blur_nhwc(x if i % 2 == 0 else y, y if i % 2 == 0 else x, taps, nt, tmp)
+
+    for _ in range(args.warmup):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    dist.barrier()
+    torch.cuda.synchronize()
+    dt = dist.max_over_ranks(time.perf_counter() - t0)
+    alg_bytes = 8.0 * B * H * W * C                              # per application
+    value = alg_bytes * apps * args.steps * world / dt / 1e9
+    ops.prof_reset()
+    ops.prof_enable(True)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    recs = ops.prof_records()
+    ops.prof_enable(False)
+    ops.prof_reset()
+    kern = {}
+    for name, ms, fl, by in recs:
+        k = kern.setdefault(name, [0, 0.0])
+        k[0] += 1; k[1] += ms
+    total_ms = sum(k[1] for k in kern.values())
+    per_app_ms = total_ms / (3 * apps)
+    ach = alg_bytes / (per_app_ms * 1e-3) / 1e9
+    # at wide kernels the banded Toeplitz product on the fp32 matrix pipe is the binding roof, not HBM: report both
+    dom = max(kern, key=lambda n: kern[n][1])
+    roof = {"bound": "hbm", "kernel": dom, "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4),
+            "traffic": hbm_traffic(f"blur{nt}", "blur256", B), "algorithmic_bytes_per_launch": round(alg_bytes),
+            "launches_per_application": len(recs) // (3 * apps), "avg_application_ms": round(per_app_ms, 5),
+            "kernels_ms_per_application": {n: round(k[1] / (3 * apps), 5) for n, k in kern.items()}}
+    if dist.rank() == 0:
+        out = {"metric": "blur GB/s (8*H*W*C bytes per image per application, 7 applications per step)", "value": round(value, 1),
+               "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"blur256: {B}x{H}x{W}x{C} per GPU, sigma {args.sigma} ({nt} taps), {apps} blur applications per step",
+                          "global_batch": B * world, "parallelism": f"dp{world}"},
+               "roofline": roof}
+        print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.shutdown()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--arch", default="celeba64", choices=["celeba64", "celeba128", "mnist"])
+    ap.add_argument("--arch", default="celeba64", choices=["celeba64", "celeba128", "mnist", "blur256"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default: 256; 128 for celeba128; 64 for mnist)")
-    ap.add_argument("--sigma", type=float, default=5.0)
+    ap.add_argument("--sigma", type=float, default=None, help="blur sigma (default: the demos' schedule start: 5 for CelebA, 0.05 for MNIST)")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: the GLOBAL batch stays 2048 (BASELINE.json configs[2]) and is "
+                    "split over the ranks, instead of 256 images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-sample-batch", type=int, default=16)
+    ap.add_argument("--cpu-sample-batch", type=int, default=None, help="batch of the CPU baseline (default: the GPU line's batch)")
     ap.add_argument("--kernels-out", default=None, help="write the full per-kernel table (and one step's launch sequence) to this JSON file")
     args = ap.parse_args()
+    if args.sigma is None:
+        args.sigma = 0.05 if args.arch == "mnist" else 5.0      # demo_mnist.py:199 (initial_blur_std), demo_celeba.py:226
 
     if args.gpus > 1 and "RANK" not in os.environ:
         # started bare with --gpus N: become the launcher (one rank per GPU over RCCL) -- as a child process, before anything
@@ -103,18 +188,24 @@ def main():
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
         sys.exit(subprocess.run(cmd).returncode)
 
+    if args.arch == "blur256":
+        return bench_blur(args)
     from blurred_gan_amd import dist, ops, callbacks
     world = dist.init_from_env()
     assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
     torch.cuda.set_device(dist.local_rank())
     B = args.batch or {"celeba64": 256, "celeba128": 128, "mnist": 64}[args.arch]
+    if args.strong:
+        gb = 2048 if args.batch is None else args.batch
+        assert gb % world == 0, f"global batch {gb} does not divide over {world} ranks"
+        B = gb // world
     gan = build_gan(args.arch, B, world, args.sigma)
     from blurred_gan_amd.models import IMAGE_SHAPE
     H, W, C = IMAGE_SHAPE[args.arch]
     g = torch.Generator(device="cuda").manual_seed(123123 + dist.rank())
     reals = torch.rand(B, H, W, C, device="cuda", generator=g) * 2 - 1
-    total_examples = 202599 * 10                                   # CelebA x 10 epochs (demo_celeba.py:135,226)
+    total_examples = (60000 if args.arch == "mnist" else 202599) * 10          # dataset x 10 epochs (demo_mnist.py:99,199; demo_celeba.py:135,226)
     ctl = callbacks.BlurDecayController(total_n_training_examples=total_examples, max_value=args.sigma)
     ctl.set_model(gan)
 
@@ -174,7 +265,7 @@ def main():
     if dist.rank() == 0:
         out = {"metric": "images/sec (G+D+GP step)", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"{args.arch} {H}x{W}x{C} batch {B}/GPU, blur sigma {args.sigma} "
                                       f"({ops.blur_policy(float(gan.std), H, W)[2]} taps), D-step+GP+G-step+Adam",
                           "global_batch": B * world, "parallelism": f"dp{world}"}}
@@ -190,7 +281,7 @@ def main():
             with open(args.kernels_out, "w") as f:
                 json.dump({"ms_per_step_sum": round(sum(k[1] for k in kern.values()) / 2, 4), "kernels": table, "sequence": seq}, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_sample_batch)
+            out["cpu_baseline"] = cpu_baseline(args.arch, args.cpu_sample_batch or B, args.sigma)
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.shutdown()

@@ -10,6 +10,7 @@
 #include "common.h"
 #include <cmath>
 #include <cstdlib>
+#include <type_traits>
 
 namespace {
 
@@ -310,6 +311,250 @@ __global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restric
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Images larger than 64 x 64 at up to 65 taps: BOTH passes in one launch, no scratch image (traffic == algorithmic + the column
+// halo, which the strips of one image share through their XCD's L2).
+//
+// A workgroup owns a strip of 32 output pixel columns of one image and streams down its rows in chunks of 32.  The two passes
+// are the banded Toeplitz products  Z = T_H (X T_W^T)  -- associativity puts the W pass first, so the H pass runs on the
+// 32-pixel-wide result instead of the haloed input and no MFMA is spent on halo columns:
+//   W pass  a chunk of 32 raw rows x (32 + 32*HB) pixels (LDS, row stride = 2 mod 4 floats with stride/2 odd: the per-channel
+//           operand reads at stride C floats are conflict-free) -> 32 rows x 32 pixels per channel, written interleaved (NHWC)
+//           into a ring of 16-row blocks;
+//   H pass  an output block of 16 rows contracts over the 2*HB + 1 ring blocks around it (ring row stride = 16 mod 32) and is
+//           computed TRANSPOSED (data as the MFMA's row operand, Toeplitz as its column operand) so that every lane ends with
+//           4 consecutive floats of one row and stores a float4.
+// v_mfma_f32_16x16x4_f32 tiles: a 16-wide output block needs 16 + taps - 1 <= 16*(2*HB + 1) source positions, against
+// 32 + taps - 1 for the 32-wide instruction (48 vs 64 at 31 taps).  The Toeplitz fragment of a lane depends only on
+// (k - n): ONE set of 4*(2*HB+1) registers, loaded once, serves every tile of both passes; each MFMA costs one ds_read_b32.
+// SAME zero padding is zeros in LDS (rows / columns outside the image load as 0), never a modified Toeplitz block.
+// The next chunk's global loads are issued into registers before the current chunk's MFMAs; two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+constexpr int kSP = 32;                                       // output pixel columns per strip
+
+// P = reach of the band on either side of a 16-wide output block, a multiple of 4 >= taps/2: the block contracts over
+// 16 + 2P source positions = 4 + P/2 k-steps of 4, every one of which carries taps.
+template <int C, int P>
+struct StripCfg {
+  static constexpr int HB = (P + 15) / 16;                    // halo blocks of 16 (columns either side of the strip, ring depth)
+  static constexpr int NQ = kSP * C;                          // output columns (floats) of a strip
+  static constexpr int XW = (kSP + 32 * HB) * C;              // input columns per row: halo of 16*HB pixels either side
+  static constexpr int XS = XW + 2;                           // XW is a multiple of 32 -> XS/2 odd
+  static constexpr int YS = NQ + 16;                          // = 16 mod 32
+  static constexpr int NK = 4 + P / 2;                        // k-steps of 4 per 16-wide output block
+  static constexpr int RB = 2 * HB + 2;                       // ring blocks of 16 rows
+  static constexpr int F4 = XW / 4;                           // float4 per input row
+  static constexpr int NLD = 32 * F4 / 256;                   // float4 per thread per chunk
+  static constexpr int TZ = 128;                              // zero-padded taps table: index k - n - P + taps/2 + 48 in [0, 128)
+  static constexpr size_t lds_bytes = ((size_t)32 * XS + (size_t)RB * 16 * YS + TZ) * sizeof(float);
+  static_assert(P % 4 == 0 && P >= 4 && P <= 32, "band reach");
+  static_assert(32 * F4 % 256 == 0, "chunk loads must divide evenly");
+};
+
+// Diagnostic build only (-DBLUR_STRIP_STAMP): wave 0 of every workgroup writes s_memtime stamps of each phase into a buffer
+// nothing else reads (the scratch pointer of bg_blur_nhwc_f32); the product build compiles none of it.
+#ifdef BLUR_STRIP_STAMP
+#define STRIP_STAMP(k) do { if (tid == 0 && j < 12) dbg[((size_t)blockIdx.x * 12 + j) * 8 + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STRIP_DBG_PARAM , unsigned long long* __restrict__ dbg
+#define STRIP_DBG_ARG , dbg
+#else
+#define STRIP_STAMP(k) do { } while (0)
+#define STRIP_DBG_PARAM
+#define STRIP_DBG_ARG
+#endif
+
+template <int C, int P>
+__global__ __launch_bounds__(256) void blur_strip_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int strips,
+                                                         const float* __restrict__ taps, int T STRIP_DBG_PARAM) {
+  using K = StripCfg<C, P>;
+  constexpr int HB = K::HB, XS = K::XS, YS = K::YS, NK = K::NK, RB = K::RB, F4 = K::F4, NLD = K::NLD;
+  constexpr int NCH = C == 1 ? 2 : C;                         // independent accumulator chains (16x16x4 has a 40-cycle dependent latency)
+  extern __shared__ __attribute__((aligned(16))) float sl[];
+  float* X = sl;                                              // [32][XS]   raw chunk
+  float* Y = sl + 32 * XS;                                    // [RB*16][YS] W-passed rows, circular
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kk = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifndef BLUR_STRIP_PRIO
+#define BLUR_STRIP_PRIO 2
+#endif
+#if BLUR_STRIP_PRIO == 1
+  if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(1);       // HW_ID[3:0]: odd wave slot
+#elif BLUR_STRIP_PRIO == 2
+  // Two workgroups share a CU, so two waves running this same program share each SIMD's matrix pipe.  Contending MFMA by MFMA
+  // they fall into lockstep (both in a chain, then both in loads / stores / barriers): the pipe is contended half of the time
+  // and idle the rest.  A static priority for the workgroup that sits SECOND in the CU's LDS (LDS_ALLOC.LDS_BASE != 0) lets
+  // its chains run as if alone; the other's chains then fall into its memory phases.
+  if (__builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6) != 0) __builtin_amdgcn_s_setprio(1);
+#endif
+  // blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): the strips of one image are consecutive there and re-use each
+  // other's halo columns from that L2 (speed only)
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int img = (idx / strips) * 8 + xcd, strip = idx - (idx / strips) * strips;
+  if (img >= B) return;
+  const int half = T >> 1, WC = W * C;
+  const int s0 = strip * kSP;
+  const int qin0 = (s0 - 16 * HB) * C;                        // first input column of the strip (may be negative)
+  const float* xi = x + (size_t)img * H * WC;
+  float* yi = y + (size_t)img * H * WC;
+  // Toeplitz fragment: element (k, n) of a band block holds taps[k - n - P + half].  Read through a zero-padded table in LDS,
+  // not straight from global memory: registers that a vector-memory load fills before the loop make the compiler wait for
+  // vmcnt(0) at their first use INSIDE the loop, i.e. for the next chunk's prefetch it has just issued.
+  float* tz = Y + RB * 16 * YS;
+  if (tid < K::TZ) tz[tid] = (tid >= 48 && tid < 48 + T) ? taps[tid - 48] : 0.f;
+  for (int e = tid; e < RB * 16 * YS; e += 256) Y[e] = 0.f;   // blocks above the image read as zero
+  __syncthreads();
+  float toep[NK];
+#pragma unroll
+  for (int s = 0; s < NK; ++s) toep[s] = tz[4 * s + kk - li - P + half + 48];
+  float4 g[NLD];
+  // chunk loader, one float4 piece at a time so that the pieces can be placed between the MFMAs of the H pass.  Buffer loads
+  // with a per-image descriptor: rows / columns outside the image take an out-of-range offset and come back as zeros (SAME
+  // padding with no branch and no select)
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xi), 0, H * WC * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(yi, 0, H * WC * 4, 0x00020000);
+  constexpr int kOob = (int)0x80000000;
+  auto gload1 = [&](int i, int row0, bool live) {
+    const int e = tid + i * 256, rr = e / F4, c4 = e - rr * F4;
+    const int r = row0 + rr, q = qin0 + 4 * c4;
+#ifdef BLUR_STRIP_NOLOAD      // knock-out experiment
+    g[i] = make_float4((float)r, (float)q, 1.f, 2.f);
+#else
+    g[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (live && r < H && q >= 0 && q < WC) ? (r * WC + q) * 4 : kOob, 0, 0));
+#endif
+  };
+  auto xstore1 = [&](int i) {
+    const int e = tid + i * 256, rr = e / F4, c4 = e - rr * F4;
+    float2* d = reinterpret_cast<float2*>(X + rr * XS + 4 * c4);         // rows are 8-byte aligned (XS even)
+    d[0] = make_float2(g[i].x, g[i].y);
+    d[1] = make_float2(g[i].z, g[i].w);
+  };
+  const int nblk = (H + 15) >> 4, n_iter = (nblk + HB + 1) >> 1;
+  // prologue: chunk 0 into LDS, chunk 1 in flight
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) gload1(i, 0, true);
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) xstore1(i);
+#pragma unroll
+  for (int i = 0; i < NLD; ++i) gload1(i, 32, true);
+  __syncthreads();
+  // Iteration j = two MFMA-paced phases with one barrier each:
+  //   W phase  chunk j (in X) -> ring blocks 2j, 2j+1
+  //   H phase  output blocks 2j-HB, 2j+1-HB from the ring; between its MFMAs the wave also moves chunk j+1 from its registers
+  //            into X (free since the barrier) and issues the loads of chunk j+2 -- every memory instruction of the kernel
+  //            except the result stores issues in the shadow of an MFMA chain
+  constexpr int OPS = (2 * NLD + NK - 1) / NK;                // memory pieces per k-step of the H pass
+  for (int j = 0; j < n_iter; ++j) {
+    STRIP_STAMP(0);
+    if (32 * j < H) {
+      // C == 3: wave -> (row block, pixel tile), one accumulator per channel; C == 1: the same tiles, the k-steps alternate
+      // between two accumulators
+      const int rb = wave >> 1, pt = wave & 1;
+      floatx4 acc[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) acc[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+      const float* xa = X + (16 * rb + li) * XS + (16 * pt + 16 * HB - P + kk) * C;
+      // all operand reads of the tile first, then the MFMA chains: the matrix pipe never waits on an LDS round trip mid-chain
+      float av[NK][C];
+#pragma unroll
+      for (int s = 0; s < NK; ++s)
+#pragma unroll
+        for (int c = 0; c < C; ++c) av[s][c] = xa[4 * s * C + c];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int s = 0; s < NK; ++s) {
+        if (C == 1) {
+          acc[s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][0], toep[s], acc[s & 1], 0, 0, 0);
+        } else {
+#pragma unroll
+          for (int c = 0; c < C; ++c) acc[c] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][c], toep[s], acc[c], 0, 0, 0);
+        }
+      }
+      if (C == 1) acc[0] += acc[1];
+      const int slot = (2 * j + rb) % RB;
+      float* yo = Y + (slot * 16 + 4 * kk) * YS + (16 * pt + li) * C;
+#pragma unroll
+      for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) yo[i * YS + c] = acc[c][i];
+    } else {
+      // below the image: the two blocks read as zero
+      for (int e = tid; e < 2 * 16 * YS; e += 256) {
+        const int blk = e / (16 * YS), r = e - blk * 16 * YS;
+        Y[((2 * j + blk) % RB) * 16 * YS + r] = 0.f;
+      }
+    }
+    STRIP_STAMP(1);
+    __syncthreads();                                           // ring blocks visible; X is free
+    STRIP_STAMP(2);
+    {
+      constexpr int NT = C == 1 ? 1 : 3;                      // column tiles of 16 per wave: 2 blocks x (NQ/16) tiles over 4 waves
+      const int ob = wave >> 1, ct0 = (wave & 1) * NT;
+      const int o = 2 * j - HB + ob;
+      const bool ld_next = 32 * (j + 2) < H;                  // past the image: out-of-range offsets, the loads return zeros
+      // straight-line body in two versions (a wave with no output block this iteration -- first / last iterations -- still moves
+      // its share of the next chunk): no branch sits between the MFMAs and the memory pieces, which would also make the
+      // compiler drain vmcnt before every piece
+      auto h_phase = [&](auto hv_) {
+        constexpr bool HV = decltype(hv_)::value;
+        floatx4 acc[NCH];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) acc[c] = floatx4{0.f, 0.f, 0.f, 0.f};
+        float bv[NK][NT];
+        if (HV) {
+          const int r0 = 16 * o - P + RB * 16;                // first band row in ring coordinates (>= 0, a multiple of 4)
+          const float* yb = Y + kk * YS + 16 * ct0 + li;
+#pragma unroll
+          for (int s = 0; s < NK; ++s) {
+            const float* yr = yb + ((r0 + 4 * s) % (RB * 16)) * YS;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) bv[s][t] = yr[16 * t];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NK; ++s) {
+          if (HV) {
+            if (C == 1) {
+              acc[s & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s][0], toep[s], acc[s & 1], 0, 0, 0);
+            } else {
+#pragma unroll
+              for (int t = 0; t < NT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[s][t], toep[s], acc[t], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int u = 0; u < OPS; ++u) {
+            const int op = s * OPS + u;                       // pieces 0..NLD-1: registers -> X; NLD..2*NLD-1: next loads
+            if (op < NLD) xstore1(op);
+            else if (op < 2 * NLD) gload1(op - NLD, 32 * (j + 2), ld_next);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (HV) {
+          if (C == 1) acc[0] += acc[1];
+          const int row = 16 * o + li;
+#pragma unroll
+          for (int t = 0; t < NT; ++t) {
+            const int q = s0 * C + 16 * (ct0 + t) + 4 * kk;   // 4 consecutive floats of one output row
+#ifdef BLUR_STRIP_NOSTORE     // knock-out experiment: keep the value live, store (almost) never
+            const bool ok = row < H && q < WC && acc[t][0] == 12345.678f;
+#else
+            const bool ok = row < H && q < WC;
+#endif
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, acc[t]), rsy,
+                                                   ok ? (row * WC + q) * 4 : kOob, 0, 0);
+          }
+        }
+      };
+      if (o >= 0 && o < nblk) h_phase(std::true_type{});
+      else h_phase(std::false_type{});
+    }
+    STRIP_STAMP(3);
+    __syncthreads();                                           // chunk j+1 visible in X; every wave is past this H pass
+    STRIP_STAMP(4);
+  }
+}
+
 // Images larger than LDS: two passes through a scratch image in HBM (traffic 2x algorithmic), each pass holding
 // whole lines along the filtered axis in LDS so no halo is ever re-read, same register sliding window.
 //   pass H: workgroup = one image x a strip of kStripW consecutive (w,c) columns, all H rows resident
@@ -426,6 +671,40 @@ __global__ __launch_bounds__(kBlurThreads) void blur_pass_kernel(const float* __
   }
 }
 
+template <int C, int P>
+int launch_strip(dim3 grid, hipStream_t s, const float* x, float* y, int B, int H, int W, int strips, const float* taps, int T, void* dbg_) {
+#ifdef BLUR_STRIP_STAMP
+  unsigned long long* dbg = static_cast<unsigned long long*>(dbg_);
+#endif
+  auto kern = blur_strip_kernel<C, P>;
+  size_t lds = StripCfg<C, P>::lds_bytes;
+  static bool attr = false;                                   // one flag per instantiation
+  if (!attr && lds > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "blur_strip: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr = true;
+  }
+#ifndef BLUR_STRIP_LDS_PAD
+#define BLUR_STRIP_LDS_PAD 1
+#endif
+#if BLUR_STRIP_LDS_PAD
+  // never three workgroups on one CU while another holds one: a grid of two rounds would run as 3 + 1 on some CU pairs and
+  // the launch would last as long as the triple (the footprint is just under a third of the 160 KiB)
+  if (3 * lds <= 160 * 1024) lds = 160 * 1024 / 3 + 1024;
+#endif
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, y, B, H, W, strips, taps, T STRIP_DBG_ARG);
+  return BG_OK;
+}
+
+template <int C>
+int launch_strip_c(int reach, dim3 grid, hipStream_t s, const float* x, float* y, int B, int H, int W, int strips, const float* taps, int T, void* dbg) {
+  if (reach <= 4) return launch_strip<C, 4>(grid, s, x, y, B, H, W, strips, taps, T, dbg);
+  if (reach <= 8) return launch_strip<C, 8>(grid, s, x, y, B, H, W, strips, taps, T, dbg);
+  if (reach <= 16) return launch_strip<C, 16>(grid, s, x, y, B, H, W, strips, taps, T, dbg);
+  if (reach <= 24) return launch_strip<C, 24>(grid, s, x, y, B, H, W, strips, taps, T, dbg);
+  return launch_strip<C, 32>(grid, s, x, y, B, H, W, strips, taps, T, dbg);
+}
+
 size_t fused_lds_bytes(int H, int W, int C) { return (2 * (size_t)(((H * W * C) + 3) & ~3) + 512) * sizeof(float); }
 constexpr size_t kFusedLdsCap = 150 * 1024;
 
@@ -472,7 +751,11 @@ int bg_gauss_kernel_1d(float sigma_eff, float kernel_size, float* taps_host, int
 //   1 whole image per workgroup, register sliding window (fits LDS, < 13 taps)  -- no scratch
 //   2 two transposing banded-Toeplitz passes (C <= 4)                           -- scratch
 //   3 line kernels / generic passes                                             -- scratch
+//   4 fused streaming strips, both passes in one launch (1 or 3 channels, <= 65 taps, larger than 64x64) -- no scratch
 static int blur_path(int B, int H, int W, int C, int n_taps) {
+  static const int strip_min = getenv("BG_BLUR_STRIP_MIN_SIZE") ? atoi(getenv("BG_BLUR_STRIP_MIN_SIZE")) : 65;
+  static const int strip_max_taps = getenv("BG_BLUR_STRIP_MAX_TAPS") ? atoi(getenv("BG_BLUR_STRIP_MAX_TAPS")) : 65;
+  if ((C == 1 || C == 3) && ((W * C) & 3) == 0 && n_taps <= std::min(strip_max_taps, 65) && (H >= strip_min || W >= strip_min)) return 4;
   static const int mfma_min_taps = getenv("BG_BLUR_MFMA_MIN_TAPS") ? atoi(getenv("BG_BLUR_MFMA_MIN_TAPS")) : 13;
   static const int band_t_min = getenv("BG_BLUR_BANDT_MIN_TAPS") ? atoi(getenv("BG_BLUR_BANDT_MIN_TAPS")) : 13;
   const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
@@ -490,7 +773,8 @@ static int blur_path(int B, int H, int W, int C, int n_taps) {
 
 size_t bg_blur_workspace_bytes(int B, int H, int W, int C, int n_taps) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
-  return blur_path(B, H, W, C, n_taps) <= 1 ? 0 : (size_t)B * H * W * C * sizeof(float);
+  const int path = blur_path(B, H, W, C, n_taps);
+  return (path <= 1 || path == 4) ? 0 : (size_t)B * H * W * C * sizeof(float);
 }
 
 int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const float* taps_d, int n_taps,
@@ -526,6 +810,15 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
                          magic((unsigned)W));
       return L.done("blur_mfma_kernel");
     }
+  }
+  if (path == 4) {
+    const int strips = (int)bg::cdiv(W, kSP);
+    const dim3 grid((unsigned)(8 * bg::cdiv(B, 8) * strips));
+    bg::Launch L(stream, "blur_strip", flops, bytes);
+    const int rc = C == 3 ? launch_strip_c<3>(n_taps >> 1, grid, s, x, y, B, H, W, strips, taps_d, n_taps, tmp_d)
+                          : launch_strip_c<1>(n_taps >> 1, grid, s, x, y, B, H, W, strips, taps_d, n_taps, tmp_d);
+    if (rc) return rc;
+    return L.done("blur_strip_kernel");
   }
   const size_t lds = fused_lds_bytes(H, W, C);
   if (path == 1) {

@@ -32,11 +32,18 @@ def collectives_active():
 
 
 def local_rank():
-    """Device index of this process.  One process per GPU; when a node exposes fewer devices than ranks (the
-    2-ranks-on-one-card rehearsal of tests/test_dp_gpu.py and of bench.py) ranks share devices round-robin."""
+    """Device index of this process: LOCAL_RANK, one process per GPU.  More local ranks than visible devices is an error (two
+    RCCL ranks on one card hang inside the first collective instead of failing) unless the rehearsal switch
+    BGAN_DIST_SHARE_DEVICES=1 or the gloo backend override is set: then ranks share devices round-robin (tests/test_dp_gpu.py)."""
     lr = int(os.environ.get("LOCAL_RANK", "0"))
     n = torch.cuda.device_count() if torch.cuda.is_available() else 0
-    return lr % n if n > 0 else lr
+    if n > 0 and lr >= n:
+        if os.environ.get("BGAN_DIST_SHARE_DEVICES") == "1" or os.environ.get("BGAN_DIST_BACKEND") == "gloo":
+            return lr % n
+        raise RuntimeError(f"LOCAL_RANK={lr} but only {n} GPU(s) are visible: launch one process per GPU "
+                           f"(--nproc-per-node <= {n}); set BGAN_DIST_SHARE_DEVICES=1 with BGAN_DIST_BACKEND=gloo to rehearse "
+                           "several ranks on one card")
+    return lr
 
 
 def init_from_env(backend=None):
@@ -55,17 +62,30 @@ def init_from_env(backend=None):
     return world_size()
 
 
+class _Done:
+    def wait(self):
+        return None
+
+
+def all_reduce_sum_async(flat):
+    """Enqueues the in-place SUM all-reduce of ``flat`` behind the kernels enqueued so far and returns a handle whose
+    ``wait()`` orders the current stream after it: work enqueued between the two overlaps the exchange (the BatchNorm
+    backward statistics travel while the layer above computes its filter gradient).  No-op for a single replica."""
+    if not collectives_active():
+        return _Done()
+    if _use_abi_comm(flat):
+        return AbiComm.get().all_reduce_async(flat)
+    if flat.is_cuda and td.get_backend() == "gloo":      # CPU-side rehearsal: stage through the host, synchronous
+        host = flat.cpu()
+        td.all_reduce(host, op=td.ReduceOp.SUM)
+        flat.copy_(host)
+        return _Done()
+    return td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=True)     # RCCL over xGMI, on RCCL's own stream
+
+
 def all_reduce_sum_(flat):
-    """In-place SUM all-reduce of a flat gradient buffer (no-op for a single replica)."""
-    if collectives_active():
-        if _use_abi_comm(flat):
-            AbiComm.get().all_reduce_async(flat).wait()
-        elif flat.is_cuda and td.get_backend() == "gloo":    # CPU test harness: stage through the host
-            host = flat.cpu()
-            td.all_reduce(host, op=td.ReduceOp.SUM)
-            flat.copy_(host)
-        else:
-            td.all_reduce(flat, op=td.ReduceOp.SUM)          # RCCL ring/tree over xGMI on the GPU box
+    """In-place SUM all-reduce of a flat buffer (no-op for a single replica)."""
+    all_reduce_sum_async(flat).wait()
     return flat
 
 
@@ -136,8 +156,12 @@ class GradReducer:
     one message per layer).  ``finish()`` reduces whatever was not reported and waits; Adam runs after it.
     With one replica every call is a no-op."""
 
-    def __init__(self, flat, n, bucket_bytes=4 << 20):
+    def __init__(self, flat, n, bucket_bytes=None):
         self.flat, self.n = flat, int(n)
+        if bucket_bytes is None:
+            # xGMI is point-to-point and a ring is bound by one link: a few 16 MB messages per network (critic 17 MB, generator
+            # 47 MB) keep the per-message latency small against the transfer and still overlap the tail of the backward
+            bucket_bytes = int(float(os.environ.get("BGAN_DP_BUCKET_MB", "16")) * (1 << 20))
         self.bucket = max(1, int(bucket_bytes) // 4)
         self.active = collectives_active()
         self.pending = None          # (lo, hi) merged, not yet issued
@@ -205,10 +229,18 @@ class GradReducer:
         self.works = []
 
 
+def _quiesce_abi():
+    """Two communicators must never have collectives in flight at once (the classic RCCL/NCCL cross-communicator deadlock):
+    before anything goes through torch's communicator, the C ABI's private stream is drained."""
+    if AbiComm._inst is not None:
+        AbiComm._inst.stream.synchronize()
+
+
 def max_over_ranks(value: float) -> float:
     """MAX of a host scalar over the replicas (bench timing)."""
     if world_size() <= 1:
         return float(value)
+    _quiesce_abi()
     dev = "cuda" if (td.get_backend() == "nccl") else "cpu"
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     td.all_reduce(t, op=td.ReduceOp.MAX)
@@ -217,12 +249,24 @@ def max_over_ranks(value: float) -> float:
 
 def broadcast_(flat, src=0):
     if world_size() > 1:
+        _quiesce_abi()
         td.broadcast(flat, src=src)
     return flat
 
 
+def broadcast_object(obj, src=0):
+    """A small Python object from rank ``src`` to everyone (run directory names in the demos)."""
+    if world_size() <= 1:
+        return obj
+    _quiesce_abi()
+    box = [obj]
+    td.broadcast_object_list(box, src=src)
+    return box[0]
+
+
 def barrier():
     if world_size() > 1:
+        _quiesce_abi()
         td.barrier()
 
 

@@ -358,6 +358,8 @@ class Net:
         B = ctx.B
         WB = B if dw_rows is None else int(dw_rows)
         g, g_is_dz = dout, False
+        sync_bn = self.sync_bn and dist.collectives_active()
+        pending_stats = None        # SyncBN: the all-reduce of the NEXT (lower) stage's backward statistics, in flight
         for i in range(len(self.stages) - 1, -1, -1):
             st = self.stages[i]
             gv = g.view(B, *st.out_shape)
@@ -369,11 +371,14 @@ class Net:
                 ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
                 dg = st_.grad_of(st.bn, "gamma") if need_dw else torch.empty(C, device=self.device)
                 db = st_.grad_of(st.bn, "beta") if need_dw else torch.empty(C, device=self.device)
-                if self.sync_bn and dist.collectives_active():
+                if sync_bn:
                     world = dist.world_size()
                     sums = ctx.bn_sums(i, C)
-                    ops.bn_bwd_stats(gv, ctx.a[i], ctx.z[i], M, C, ctx.mean[i], ctx.inv[i], sums, ws, lrelu_alpha=st.alpha)
-                    dist.all_reduce_sum_(sums)
+                    if pending_stats is None:       # last stage: nothing above it to overlap with
+                        ops.bn_bwd_stats(gv, ctx.a[i], ctx.z[i], M, C, ctx.mean[i], ctx.inv[i], sums, ws, lrelu_alpha=st.alpha)
+                        pending_stats = dist.all_reduce_sum_async(sums)
+                    pending_stats.wait()            # issued before the filter gradient of the stage above: it travelled meanwhile
+                    pending_stats = None
                     ops.bn_bwd_apply(gv, ctx.a[i], ctx.z[i], dz, M, M * world, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], sums,
                                      lrelu_alpha=st.alpha)
                     if need_dw:     # the sums are already global: pre-divide so the flat gradient SUM all-reduce restores them
@@ -405,8 +410,9 @@ class Net:
             ctx.dz[i] = dz
             xin = ctx.xin[i]
             lin = st.lin
-            # ---- weight gradients
-            if need_dw:
+            prev = self.stages[i - 1] if i > 0 else None
+
+            def weight_grads():
                 dW = st_.grad_of(lin, "kernel")
                 xw, dzw = (xin, dz) if WB == B else (xin[:WB], dz.view(B, *st.out_shape)[:WB])
                 if st.kind == "dense":
@@ -429,16 +435,25 @@ class Net:
                     ops.colsum(dzw, st_.grad_of(lin, "bias"), rows, N, ws, beta=beta, scale=scale)
                 if reducer is not None:
                     reducer.ready(*st_.train_range(lin, st.bn))
+
+            # SyncBN with a BatchNorm stage below: the data gradient goes FIRST, the lower stage's backward statistics are
+            # reduced and their all-reduce is put in flight, and only then this stage's filter gradient runs -- the small
+            # latency-bound collective hides behind an MFMA kernel instead of sitting on the critical path of every layer.
+            # (The filter gradient's split-K workspace and the statistics' partials share net.workspace(): the statistics
+            # kernel has finished with it before the filter gradient is enqueued on the same stream.)
+            overlap = sync_bn and need_dw and prev is not None and prev.bn is not None
+            if need_dw and not overlap:
+                weight_grads()
             # ---- input gradient
             if i == 0 and not need_dx:
                 return None
-            prev = self.stages[i - 1] if i > 0 else None
             fuse = prev is not None and prev.fusable_grad and st.kind != "dense"
             tgt = ctx.buf(ctx.dz, i - 1).view(B, *st.in_shape) if i > 0 else ctx.input_grad().view(B, *st.in_shape)
             Bx = B
+            dzx = dz
             if i == 0 and dx_rows is not None:        # the image gradient is wanted for samples [lo, hi) only
                 lo, hi = dx_rows
-                dz = dz.view(B, *st.out_shape)[lo:hi]
+                dzx = dz.view(B, *st.out_shape)[lo:hi]
                 tgt = tgt[lo:hi]
                 Bx = hi - lo
             epi = None
@@ -456,11 +471,20 @@ class Net:
                     epi = self._epi(*geom, EPI_NONE)
             if st.kind == "dense":
                 K, N = st.in_shape[0], st.out_shape[0]
-                ops.gemm(dz, lin.vars["kernel"], tgt, Bx, K, N, transB=True)
+                ops.gemm(dzx, lin.vars["kernel"], tgt, Bx, K, N, transB=True)
             elif st.kind == "conv":
-                ops.conv2d_bwd_data(dz, lin.vars["kernel"], tgt, lin.k, lin.stride, epi)
+                ops.conv2d_bwd_data(dzx, lin.vars["kernel"], tgt, lin.k, lin.stride, epi)
             else:
-                ops.conv2d_fwd(dz, self.store.transposed_kernel(lin), tgt, lin.k, lin.stride, epi)
+                ops.conv2d_fwd(dzx, self.store.transposed_kernel(lin), tgt, lin.k, lin.stride, epi)
+            if overlap:
+                Cp = prev.out_shape[-1]
+                gp = tgt.view(B, *prev.out_shape)
+                Mp = gp.numel() // Cp
+                sums = ctx.bn_sums(i - 1, Cp)
+                ops.bn_bwd_stats(gp, ctx.a[i - 1], ctx.z[i - 1], Mp, Cp, ctx.mean[i - 1], ctx.inv[i - 1], sums,
+                                 self.workspace(ops._lib.load().bg_bn_workspace_bytes(Mp, Cp)), lrelu_alpha=prev.alpha)
+                pending_stats = dist.all_reduce_sum_async(sums)
+                weight_grads()
             g, g_is_dz = tgt, fuse
         din = g
         if self.blur is not None:

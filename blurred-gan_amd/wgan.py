@@ -105,6 +105,13 @@ class WGAN:
                  config: TrainingConfig, *args, reproduce_vector_loss_quirk: bool = True, sync_metrics: bool = True,
                  sync_batchnorm: bool = True, merge_critic_passes: bool = True, **kwargs):
         self.hparams = hyperparams
+        if dist.world_size() > 1 and int(hyperparams.global_batch_size) != int(hyperparams.batch_size) * dist.world_size():
+            import warnings
+            # Q2: the reference never writes the true global batch into the hyper-parameters; under data parallelism the loss
+            # scale 1/global_batch_size and the penalty's global mean must agree, so say so instead of training a different model
+            warnings.warn(f"global_batch_size={hyperparams.global_batch_size} but {dist.world_size()} replicas x batch_size="
+                          f"{hyperparams.batch_size}: the Wasserstein / penalty gradient ratio differs from the single-device "
+                          "step at the global batch (set global_batch_size = batch_size * replicas)")
         if str(self.hparams.optimizer).lower() != "adam":
             raise NotImplementedError("only the reference's default optimizer 'adam' is implemented (wgan.py:43,56)")
         self.generator = generator

@@ -59,37 +59,51 @@ class DCGANDiscriminator(layers.Sequential):
         self.add(layers.Dense(1, activation="linear"))
 
 
-if __name__ == "__main__":
+def main(argv=None):
+    """demo_celeba.py:127-246; multi-GPU decisions as in demo_mnist.main (global batch = per-GPU batch x replicas, one run
+    directory made by rank 0, file-writing callbacks on rank 0 only)."""
     blurred_gan.set_seed(123123)
     parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     BlurredWGANGP.HyperParameters.add_arguments(parser)
     TrainingConfig.add_arguments(parser)
     parser.add_argument("--epochs", type=int, default=10)
     parser.add_argument("--max_batches", type=int, default=None)
-    args = parser.parse_args()
+    parser.add_argument("--results_dir", default="results")
+    args = parser.parse_args(argv)
     hyperparameters = BlurredWGANGP.HyperParameters.from_args(args)
     config = TrainingConfig.from_args(args)
-    num_gpus = blurred_gan.dist.init_from_env()
-    print("Num gpus:", num_gpus)
-    dataset = make_dataset(hyperparameters.batch_size, n_batches=args.max_batches, seed=blurred_gan.dist.rank())
+    dist = blurred_gan.dist
+    num_gpus = dist.init_from_env()
+    rank0 = dist.rank() == 0
+    if rank0:
+        print("Num gpus:", num_gpus)
+    hyperparameters.global_batch_size = hyperparameters.batch_size * num_gpus
+    dataset = make_dataset(hyperparameters.batch_size, n_batches=args.max_batches, seed=dist.rank())
     total_n_examples = 202_599
-    config.log_dir = utils.create_result_subdir("results", "celeba")
+    config.log_dir = dist.broadcast_object(utils.create_result_subdir(args.results_dir, "celeba") if rank0 else None)
     config.checkpoint_dir = config.log_dir + "/checkpoints"
     gen, disc = DCGANGenerator(), DCGANDiscriminator()
     gan = blurred_gan.BlurredWGANGP(gen, disc, hyperparams=hyperparameters, config=config)
     manager = CheckpointManager(gan, directory=config.checkpoint_dir, max_to_keep=5)
     if manager.latest_checkpoint:
         manager.restore(manager.latest_checkpoint)
-    gan.hparams.save_json(os.path.join(config.log_dir, "hyper_parameters.json"))
-    gan.config.save_json(os.path.join(config.log_dir, "train_config.json"))
+    cbs = [callbacks.BlurDecayController(total_n_training_examples=total_n_examples * args.epochs, max_value=5)]
+    if rank0:
+        gan.hparams.save_json(os.path.join(config.log_dir, "hyper_parameters.json"))
+        gan.config.save_json(os.path.join(config.log_dir, "train_config.json"))
+        cbs = [callbacks.GenerateSampleGridCallback(log_dir=config.log_dir, every_n_examples=5_000), *cbs,
+               callbacks.SaveModelCallback(manager, n=10_000), callbacks.LogMetricsCallback()]
     try:
-        gan.fit(x=dataset, y=None, epochs=args.epochs, initial_epoch=gan.n_img // total_n_examples,
-                callbacks=[
-                    callbacks.GenerateSampleGridCallback(log_dir=config.log_dir, every_n_examples=5_000),
-                    callbacks.BlurDecayController(total_n_training_examples=total_n_examples * args.epochs, max_value=5),
-                    callbacks.SaveModelCallback(manager, n=10_000),
-                    callbacks.LogMetricsCallback(),
-                ])
+        gan.fit(x=dataset, y=None, epochs=args.epochs, initial_epoch=gan.n_img // total_n_examples, callbacks=cbs)
     except KeyboardInterrupt:
-        manager.save()
-    print("Done training.")
+        if rank0:
+            manager.save()
+    dist.barrier()
+    if rank0:
+        print("Done training.")
+    return gan
+
+
+if __name__ == "__main__":
+    main()
+    blurred_gan.dist.shutdown()

@@ -64,26 +64,34 @@ class DCGANDiscriminator(layers.Sequential):
         self.add(layers.Dense(1))
 
 
-if __name__ == "__main__":
+def main(argv=None):
+    """demo_mnist.py:91-219.  Under ``torchrun`` (one process per GPU) every rank trains on its own shard; what the reference
+    leaves undone for multi-GPU (demo_mnist.py:116 "TODO") is decided here: ``global_batch_size`` = per-GPU batch x replicas
+    (wgan.py:130,157 scale the losses by it), ONE run directory created by rank 0 and shared, and the host-side callbacks that
+    write files (checkpoints, sample grids, scalar logs) on rank 0 only."""
     blurred_gan.set_seed(123123)
     parser = argparse.ArgumentParser(formatter_class=argparse.ArgumentDefaultsHelpFormatter)
     BlurredWGANGP.HyperParameters.add_arguments(parser)
     TrainingConfig.add_arguments(parser)
     parser.add_argument("--epochs", type=int, default=10)
     parser.add_argument("--max_batches", type=int, default=None, help="truncate the epoch (smoke runs)")
-    args = parser.parse_args()
+    parser.add_argument("--results_dir", default="results")
+    args = parser.parse_args(argv)
     hyperparameters = BlurredWGANGP.HyperParameters.from_args(args)
     config = TrainingConfig.from_args(args)
-    print(hyperparameters)
-    print(config)
 
-    num_gpus = blurred_gan.dist.init_from_env()
-    print("Num gpus:", num_gpus)
+    dist = blurred_gan.dist
+    num_gpus = dist.init_from_env()
+    rank0 = dist.rank() == 0
+    if rank0:
+        print(hyperparameters)
+        print(config)
+        print("Num gpus:", num_gpus)
     batch_size_per_gpu = hyperparameters.batch_size
-    dataset = make_dataset(batch_size_per_gpu, n_batches=args.max_batches, seed=blurred_gan.dist.rank())
+    hyperparameters.global_batch_size = batch_size_per_gpu * num_gpus          # demo_mnist.py:123 computes it and forgets to store it
+    dataset = make_dataset(batch_size_per_gpu, n_batches=args.max_batches, seed=dist.rank())
     total_n_examples = 60_000
-    results_dir = "results"
-    config.log_dir = utils.create_result_subdir(results_dir, "mnist")
+    config.log_dir = dist.broadcast_object(utils.create_result_subdir(args.results_dir, "mnist") if rank0 else None)
     config.checkpoint_dir = config.log_dir + "/checkpoints"
 
     gen = DCGANGenerator()
@@ -93,19 +101,26 @@ if __name__ == "__main__":
     if manager.latest_checkpoint:
         manager.restore(manager.latest_checkpoint)
         print(f"Model was previously trained on {gan.n_img.numpy()} images")
-    gan.hparams.save_json(os.path.join(config.log_dir, "hyper_parameters.json"))
-    gan.config.save_json(os.path.join(config.log_dir, "train_config.json"))
+    cbs = [callbacks.BlurDecayController(total_n_training_examples=total_n_examples * args.epochs,
+                                         max_value=hyperparameters.initial_blur_std)]
+    if rank0:
+        gan.hparams.save_json(os.path.join(config.log_dir, "hyper_parameters.json"))
+        gan.config.save_json(os.path.join(config.log_dir, "train_config.json"))
+        cbs = [callbacks.GenerateSampleGridCallback(log_dir=config.log_dir, every_n_examples=5_000), *cbs,
+               callbacks.SaveModelCallback(manager, n=10_000), callbacks.LogMetricsCallback()]
     try:
-        gan.fit(x=dataset, y=None, epochs=args.epochs, initial_epoch=gan.n_img // total_n_examples,
-                callbacks=[
-                    callbacks.GenerateSampleGridCallback(log_dir=config.log_dir, every_n_examples=5_000),
-                    callbacks.BlurDecayController(total_n_training_examples=total_n_examples * args.epochs,
-                                                  max_value=hyperparameters.initial_blur_std),
-                    callbacks.SaveModelCallback(manager, n=10_000),
-                    callbacks.LogMetricsCallback(),
-                ])
+        gan.fit(x=dataset, y=None, epochs=args.epochs, initial_epoch=gan.n_img // total_n_examples, callbacks=cbs)
     except KeyboardInterrupt:
-        manager.save()
-    print("Done training.")
-    samples = gan.generate_samples()
-    print(tuple(samples.shape))
+        if rank0:
+            manager.save()
+    dist.barrier()
+    if rank0:
+        print("Done training.")
+        samples = gan.generate_samples()
+        print(tuple(samples.shape))
+    return gan
+
+
+if __name__ == "__main__":
+    main()
+    blurred_gan.dist.shutdown()

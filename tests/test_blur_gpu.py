@@ -27,6 +27,10 @@ def _run(x, std):
     ((1, 256, 256, 3), 42.34), ((2, 12, 12, 1), 0.7), ((2, 5, 7, 2), 2.0),
     ((2, 100, 72, 3), 3.0), ((1, 218, 178, 3), 5.0), ((3, 96, 80, 1), 8.0), ((2, 130, 66, 2), 30.0), ((1, 218, 178, 3), 40.0),
     ((2, 128, 128, 4), 5.0), ((3, 160, 144, 1), 6.0), ((2, 128, 128, 3), 1.0), ((2, 192, 136, 2), 2.0),   # band passes at narrow kernels, 1 / 2 / 4 channels   # line kernels / banded Toeplitz passes (>= 100 taps), ragged blocks
+    # fused streaming strips (1 / 3 channels, <= 65 taps, larger than 64 pixels): 3..65 taps, both halo widths, heights that are
+    # not a multiple of 16 / 32, widths that end in a partial strip, more images than XCDs and fewer
+    ((2, 256, 256, 3), 5.0), ((1, 256, 256, 3), 10.5), ((1, 256, 256, 3), 5.4), ((11, 72, 40, 1), 5.0), ((3, 300, 260, 3), 4.0),
+    ((2, 66, 100, 3), 0.05), ((9, 130, 68, 3), 2.0), ((2, 257, 96, 1), 10.0), ((1, 90, 28, 1), 1.0),
 ])
 def test_blur_matches_oracle(shape, std):
     rng = np.random.default_rng(0)
@@ -93,14 +97,14 @@ def test_blur_properties_full_size():
 @pytest.mark.parametrize("shape,std", [((128, 128, 128, 3), 5.0), ((64, 256, 256, 3), 5.0), ((64, 256, 256, 3), 23.5), ((64, 256, 256, 3), 42.34)])
 def test_blur_properties_c4_c5_sizes(shape, std):
     """The same size-independent properties at BASELINE.json's C4 (128x128, batch 128) and C5 (256x256, 64 per GPU; 31 / 143 / 255
-    taps) sizes, which run the two transposing band passes through the scratch image."""
+    taps) sizes: the fused streaming strips at 31 taps, the two transposing band passes through the scratch image above 65."""
     from blurred_gan_amd import ops
     torch.manual_seed(1)
     B, H, W, C = shape
     ks, se, nt = ops.blur_policy(std, H, W)
     taps = torch.tensor(ops.gauss_kernel_1d(se, ks), device="cuda")
     tmp = torch.empty(shape, device="cuda")
-    assert ops.blur_workspace_bytes(B, H, W, C, nt) == tmp.numel() * 4
+    assert ops.blur_workspace_bytes(B, H, W, C, nt) == (0 if nt <= 65 else tmp.numel() * 4)   # <= 65 taps: fused strips, no scratch image
     x = torch.rand(shape, device="cuda") * 2 - 1
     y = torch.rand(shape, device="cuda") * 2 - 1
     bl = lambda t: ops.blur_nhwc(t.contiguous(), torch.empty_like(t), taps, nt, tmp)

@@ -157,3 +157,30 @@ def test_rccl_path_single_rank_matches_plain_step(tmp_path):
         got_t, got_g = np.load(tmp_path / f"rccl_{tag}_theta.npy"), np.load(tmp_path / f"rccl_{tag}_grad.npy")
         np.testing.assert_allclose(got_g, ref_g, rtol=2e-3, atol=2e-4 * np.abs(ref_g).max())
         np.testing.assert_allclose(got_t, ref_t, rtol=1e-3, atol=2e-4)
+
+
+def _demo_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      BGAN_DIST_BACKEND="gloo", BGAN_DIST_SHARE_DEVICES="1")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import demo_mnist
+    gan = demo_mnist.main(["--batch_size", "4", "--epochs", "1", "--max_batches", "3", "--results_dir", os.path.join(out_dir, "results")])
+    assert int(gan.n_batches) == 3 and gan.hparams.global_batch_size == 8
+    for tag, net in (("d", gan.discriminator), ("g", gan.generator)):
+        np.save(os.path.join(out_dir, f"demo_{tag}_theta_{rank}.npy"), net.store.theta.cpu().numpy())
+    torch.distributed.destroy_process_group()
+
+
+def test_demo_under_two_ranks_one_run_directory_and_lockstep_replicas(tmp_path):
+    """The demo's fit() as two data-parallel ranks (gloo rendezvous, both on the test box's one card): the global batch is
+    written into the hyper-parameters, ONE run directory exists (made by rank 0, its name broadcast), only rank 0 wrote files,
+    and the replicas end with identical weights."""
+    import json
+    mp.spawn(_demo_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    runs = os.listdir(tmp_path / "results")
+    assert runs == ["01-mnist"], runs
+    hp = json.load(open(tmp_path / "results" / "01-mnist" / "hyper_parameters.json"))
+    assert hp["global_batch_size"] == 8 and hp["batch_size"] == 4
+    for tag in ("d", "g"):
+        np.testing.assert_array_equal(np.load(tmp_path / f"demo_{tag}_theta_0.npy"), np.load(tmp_path / f"demo_{tag}_theta_1.npy"))
