@@ -236,24 +236,29 @@ def main():
         for _ in range(nprof):
             step()
         torch.cuda.synchronize()
-        recs = ops.prof_records()
+        recs = ops.prof_records(with_exec=True)
         ops.prof_enable(False)
         ops.prof_reset()
-        for name, ms, fl, by in recs:
-            k = kern.setdefault(name, [0, 0.0, 0.0, 0.0])
-            k[0] += 1; k[1] += ms; k[2] += fl; k[3] += by
+        for name, ms, fl, by, ex in recs:
+            k = kern.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
+            k[0] += 1; k[1] += ms; k[2] += fl; k[3] += by; k[4] += ex
         # every conv kernel family runs on the MFMA pipe (gather-GEMM, row-staged, filter-gradient) except the direct fallback;
         # their split-K / slab reduce passes are counted with them
         mfma = {n: k for n, k in kern.items() if n.startswith("conv_") and n != "conv_wgrad_direct"}
         if mfma:
             dom = max(mfma, key=lambda n: mfma[n][1])
-            cnt, ms, fl, by = mfma[dom]
+            cnt, ms, fl, by, ex = mfma[dom]
             ach = fl / (ms * 1e-3) / 1e12
+            ach_x = ex / (ms * 1e-3) / 1e12
             traffic = hbm_traffic(dom, args.arch, B)
             all_ms = sum(k[1] for k in mfma.values())
             all_fl = sum(k[2] for k in mfma.values())
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4),
+                    # the same launches priced by the MFMA flops they ISSUE: whole tiles (padding rows / columns in), minus the
+                    # zero-padding taps that position-major tiles skip -- how busy the matrix pipe is, not how useful
+                    "executed": {"achieved": round(ach_x, 3), "frac": round(ach_x / PEAK_MFMA_F32_TFLOPS, 4)},
+                    "traffic": traffic,
                     "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_k_hbm_traffic.json)" if traffic else None,
                     "algorithmic_bytes_per_launch": round(by / cnt) if by else None,
                     "launches_per_step": cnt // nprof, "avg_launch_ms": round(ms / cnt, 5),
@@ -277,7 +282,7 @@ def main():
         if kern and args.kernels_out:
             table = [{"kernel": n, "launches_per_step": k[0] / 2, "ms_per_step": round(k[1] / 2, 5),
                       "tflops": round(k[2] / (k[1] * 1e-3) / 1e12, 2) if k[2] else None} for n, k in sorted(kern.items(), key=lambda kv: -kv[1][1])]
-            seq = [{"kernel": n, "us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 3)} for n, ms, fl, _ in recs[:len(recs) // 2]]
+            seq = [{"kernel": n, "us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 3)} for n, ms, fl, _, _ in recs[:len(recs) // 2]]
             with open(args.kernels_out, "w") as f:
                 json.dump({"ms_per_step_sum": round(sum(k[1] for k in kern.values()) / 2, 4), "kernels": table, "sequence": seq}, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:

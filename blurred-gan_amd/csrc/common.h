@@ -13,6 +13,7 @@ void set_error(const char* fmt, ...);
 bool prof_on();
 void prof_begin(hipStream_t s, const char* name, double flops, double bytes);
 void prof_end(hipStream_t s);
+void prof_exec_flops(double f);      // flops the launch ISSUES on the matrix pipe (tile padding in, skipped padding taps out)
 
 inline int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -35,6 +36,9 @@ struct Launch {
   Launch(void* stream, const char* name, double flops = 0, double bytes = 0)
       : s(static_cast<hipStream_t>(stream)), prof(prof_on()) {
     if (prof) prof_begin(s, name, flops, bytes);
+  }
+  void exec_flops(double f) {
+    if (prof) prof_exec_flops(f);
   }
   int done(const char* what) {
     hipError_t e = hipGetLastError();

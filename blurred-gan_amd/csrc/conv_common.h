@@ -191,9 +191,6 @@ __device__ inline float apply_epilogue_pre(const P& p, float v, size_t idx, floa
 int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B, int H, int W, int Cin, int Cout, int k, int s,
                   const bg_epilogue* epi, void* stream, int* taken);
 
-// conv_igemm_x6.hip: experimental split-bf16 (3 pieces, 6 cross terms) gather-GEMM, opt-in by BGAN_CONV_MATH=bf16x6
-int try_conv_x6(GatherParams& p, void* stream, const char* name, int* taken);
-
 // conv_c16.hip: row-staged kernels for the 16-channel layers of the 128x128 stacks (k = 5, s = 2)
 int try_conv_c16(int bwd_data, const float* a, const float* w, float* c, int B, int H, int W, int Cin, int Cout, int k, int s,
                  const bg_epilogue* epi, void* stream, int* taken);

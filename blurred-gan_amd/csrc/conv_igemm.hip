@@ -725,6 +725,30 @@ double gather_flops(const GatherParams& p) {
   return f;
 }
 
+// Flops the launch ISSUES on the matrix pipe: every workgroup runs whole BM x BN MFMA tiles (row and column padding
+// included) over its compact tap list -- position-major tiles drop the taps that are zero padding at their output position.
+double gather_exec_flops(const GatherParams& p, int BM, int BN) {
+  const double ntile = (double)bg::cdiv(p.N, BN) * BN;
+  double f = 0;
+  for (int i = 0; i < p.nphase; ++i) {
+    const GatherPhase& g = p.ph[i];
+    const long Mph = (long)p.B * g.Ha * g.Wa;
+    if (!p.pos_major) {
+      f += 2.0 * (double)bg::cdiv(Mph, BM) * BM * ntile * p.Ck * g.ntaps;
+      continue;
+    }
+    for (int ay = 0; ay < g.Ha; ++ay)
+      for (int ax = 0; ax < g.Wa; ++ax) {
+        const int sy = ay * p.ss, sx = ax * p.ss;                            // the anchor in source space (decode_row)
+        int live = 0;
+        for (int t = 0; t < g.ntaps; ++t)
+          live += ((unsigned)(sy + bg::tap_dy(g.tap[t])) < (unsigned)p.Hs && (unsigned)(sx + bg::tap_dx(g.tap[t])) < (unsigned)p.Ws) ? 1 : 0;
+        f += 2.0 * (double)p.B * ntile * p.Ck * live;
+      }
+  }
+  return f;
+}
+
 // split-K plan for small-M layers: fewer than 2 workgroups per CU and a long contraction
 int plan_splitk(const GatherParams& p, int bm, int bn, int bk) {
   const long wgs = (long)bg::cdiv(max_phase_m(p), bm) * bg::cdiv(p.N, bn) * p.nphase;
@@ -802,6 +826,7 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
   dim3 grid(p.mtiles * bg::cdiv(p.N, BN), 1, (p.nphase / p.pmerge) * ks);
   {
     bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
+    if (L.prof) L.exec_flops(gather_exec_flops(p, BM, BN));
     hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
     int rc = L.done(name);
     if (rc || ks == 1) return rc;
@@ -858,11 +883,6 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     p.a_bytes = (unsigned)a_bytes;
     p.w_bytes = (unsigned)w_bytes;
     snprintf(name, sizeof name, "conv_igemm_%s", tag);
-    {
-      int taken = 0;
-      const int rc = bg::try_conv_x6(p, stream, name, &taken);   // experiment, off unless BGAN_CONV_MATH=bf16x6
-      if (rc || taken) return rc;
-    }
     static const int force_bk = getenv("BG_IGEMM_BK") ? atoi(getenv("BG_IGEMM_BK")) : 0;   // tuning aid
     return (p.Ck % 32 == 0 && force_bk != 16) ? dispatch_igemm<32>(p, epi, stream, name) : dispatch_igemm<16>(p, epi, stream, name);
   }

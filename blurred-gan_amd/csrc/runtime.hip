@@ -17,7 +17,7 @@ void set_error(const char* fmt, ...) {
 
 struct ProfRec {
   std::string name;
-  double flops, bytes;
+  double flops, bytes, exec_flops;
   hipEvent_t e0, e1;
 };
 static bool g_prof = false;
@@ -32,10 +32,16 @@ void prof_begin(hipStream_t s, const char* name, double flops, double bytes) {
   r.name = name;
   r.flops = flops;
   r.bytes = bytes;
+  r.exec_flops = flops;          // until the launcher says otherwise (prof_exec_flops)
   (void)hipEventCreate(&r.e0);
   (void)hipEventCreate(&r.e1);
   (void)hipEventRecord(r.e0, s);
   g_recs.push_back(r);
+}
+
+void prof_exec_flops(double f) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_recs.empty()) g_recs.back().exec_flops = f;
 }
 
 void prof_end(hipStream_t s) {
@@ -100,6 +106,13 @@ int bg_prof_get(int i, char* name, int name_cap, float* ms, double* flops, doubl
   if (ms) *ms = t;
   if (flops) *flops = r.flops;
   if (bytes) *bytes = r.bytes;
+  return BG_OK;
+}
+
+int bg_prof_get_exec(int i, double* exec_flops) {
+  std::lock_guard<std::mutex> lk(bg::g_mu);
+  if (i < 0 || i >= (int)bg::g_recs.size()) return bg::fail(BG_ERR_BAD_SHAPE, "bg_prof_get_exec: index %d out of range", i);
+  if (exec_flops) *exec_flops = bg::g_recs[i].exec_flops;
   return BG_OK;
 }
 

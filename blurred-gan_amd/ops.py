@@ -340,13 +340,19 @@ def prof_reset():
     _lib.load().bg_prof_reset()
 
 
-def prof_records():
+def prof_records(with_exec=False):
+    """[(name, ms, algorithmic flops, algorithmic bytes)] per recorded launch; with_exec appends the flops the launch issued
+    on the matrix pipe (bg_prof_get_exec)."""
     lib = _lib.load()
     n = lib.bg_prof_count()
     out = []
     name = C.create_string_buffer(128)
-    ms, fl, by = C.c_float(), C.c_double(), C.c_double()
+    ms, fl, by, ex = C.c_float(), C.c_double(), C.c_double(), C.c_double()
     for i in range(n):
         check(lib.bg_prof_get(i, name, 128, C.byref(ms), C.byref(fl), C.byref(by)), "bg_prof_get")
-        out.append((name.value.decode(), ms.value, fl.value, by.value))
+        rec = (name.value.decode(), ms.value, fl.value, by.value)
+        if with_exec:
+            check(lib.bg_prof_get_exec(i, C.byref(ex)), "bg_prof_get_exec")
+            rec = rec + (ex.value,)
+        out.append(rec)
     return out

@@ -50,6 +50,9 @@ int bg_prof_enable(int on);                       /* record an event pair around
 int bg_prof_reset(void);
 int bg_prof_count(void);                          /* synchronises the recorded events          */
 int bg_prof_get(int i, char* name, int name_cap, float* ms, double* flops, double* bytes);
+/* flops record i ISSUED on the matrix pipe: whole MFMA tiles (row / column padding counted), minus the padding taps the
+   position-major tiles skip.  Equals the algorithmic figure of bg_prof_get for kernels that do not report their own. */
+int bg_prof_get_exec(int i, double* exec_flops);
 
 /* ---- Gaussian blur: gaussian_blur.py:15-132 ---------------------------------------------- */
 /* gaussian_blur.py:21-31,58-72 (appropriate_kernel_size, appropriate_std, clip, max): host maths, float32. */

@@ -153,8 +153,10 @@ def test_celeba64_batch256_step_matches_oracle():
     gan.discriminator.optimizer.learning_rate = 0.0
     gan.generator.optimizer.learning_rate = 0.0
     got = dict(zip(gan.metrics_names, gan.train_on_batch(reals.astype(np.float32), randomness=rnd)))
+    # critic: each filter-gradient element sums 2 * 256 * Ho * Wo products in float32 (up to 5e5 terms on the first layers):
+    # atol 4e-4 of the variable's largest entry, twice the batch-64 figure (measured worst case here: 2.2e-4)
     for a, b in zip(product_grads(gan.discriminator), oracle_grad_list(dg)):
-        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=2e-4 * max(np.abs(b).max(), 1e-6))
+        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=4e-4 * max(np.abs(b).max(), 1e-6))
     for a, b in zip(product_grads(gan.generator), oracle_grad_list(gg)):
         np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=1e-2 * max(np.abs(b).max(), 1e-6))
     np.testing.assert_allclose(gan.images[0].cpu().numpy(), fakes, rtol=1e-4, atol=1e-5)
