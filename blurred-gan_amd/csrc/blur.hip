@@ -190,23 +190,43 @@ __global__ __launch_bounds__(kMfmaBlurThreads) void blur_mfma_kernel(const float
 // MFMA columns, so the transposed store of one pixel column is 32*C contiguous floats.  Source rows stream through LDS in chunks
 // of 32 (float4 loads, double-buffered, shared by the four waves: every source element is fetched once per workgroup); a wave
 // skips the chunks outside its own band.
-constexpr int kBtRows = 128, kBtChunk = 32, kBtStride = 132, kBtPad = 64;
+constexpr int kBtRows = 128, kBtChunk = 32, kBtPad = 64;
+
+// Geometry: a wave owns ONE MFMA column tile of 32 floats for all four 32-row blocks of the workgroup (equal band structure in
+// every wave: nobody idles at the chunk barriers).  The workgroup's column span is a whole number of pixels: 4 tiles = 128 / C
+// pixels for 1, 2 and 4 channels; for 3 channels THREE tiles = 96 floats = 32 pixels (192-thread workgroups) -- no MFMA column
+// is padding (10-pixel tiles would idle 2 of 32), a 256-pixel line is 8 groups with no ragged last group, and 64 x 256x256x3
+// is 1024 workgroups = 4 per CU on every CU (7 groups of 40 pixels were 896: 3.5 per CU, the launch as long as the CUs with 4).
+template <int C>
+struct BandCfg {
+  static constexpr int NW = C == 3 ? 3 : 4;                   // waves = MFMA column tiles per workgroup
+  static constexpr int NTH = NW * 64;
+  static constexpr int COLS = NW * 32;                        // floats per workgroup row
+  static constexpr int PXW = COLS / C;                        // whole pixels per workgroup
+  static constexpr int STRIDE = COLS + 4;                     // LDS row stride of a source chunk
+  static constexpr int RUN = 32 * C + 4;                      // one pixel column of a transposed 32-row block (+ pad)
+  static constexpr int CHUNK = 2 * kBtChunk * STRIDE;         // double-buffered source chunks (floats)
+  static constexpr int TT = PXW * RUN;                        // transposed block of the whole workgroup
+  static constexpr int BUF = CHUNK > TT ? CHUNK : TT;
+  static_assert(COLS % C == 0, "workgroup span must be whole pixels");
+};
 
 template <int C>        // channel count as a compile-time constant: every index division below is by a constant
-__global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int S,
-                                                          int row_groups, int col_groups, const float* __restrict__ taps, int T) {
+__global__ __launch_bounds__(BandCfg<C>::NTH) void blur_band_t_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int S,
+                                                                        int row_groups, int col_groups, const float* __restrict__ taps, int T) {
+  using G = BandCfg<C>;
+  constexpr int NW = G::NW, NTH = G::NTH, COLS = G::COLS, PXW = G::PXW, STRIDE = G::STRIDE, RUN = G::RUN;
   extern __shared__ __attribute__((aligned(16))) float tl[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = T >> 1, Q = S * C;
   float* tz = tl;                                              // [64 zeros][T][64 zeros]
-  float* Bs = tl + ((T + 2 * kBtPad + 3) & ~3);                // [2][32][132] source chunks; later 4 x [32][33] transpose tiles
-  for (int j = tid; j < T + 2 * kBtPad; j += 256) tz[j] = (j >= kBtPad && j < kBtPad + T) ? taps[j - kBtPad] : 0.f;
+  float* Bs = tl + ((T + 2 * kBtPad + 3) & ~3);                // [2][32][STRIDE] source chunks; later the transposed block
+  for (int j = tid; j < T + 2 * kBtPad; j += NTH) tz[j] = (j >= kBtPad && j < kBtPad + T) ? taps[j - kBtPad] : 0.f;
   const int per_img = row_groups * col_groups;
   const int b = blockIdx.x / per_img, u = blockIdx.x - b * per_img;
   const int rg = u / col_groups, cg = u - rg * col_groups;
-  constexpr int PX = 32 / C, NQ = PX * C;                      // whole pixels / columns per MFMA tile
-  const int r0 = rg * kBtRows, s0 = cg * 4 * PX;
-  const int q0 = s0 * C, ncols = min(4 * NQ, Q - q0);          // this workgroup's source / output columns
+  const int r0 = rg * kBtRows, s0 = cg * PXW;
+  const int q0 = s0 * C, ncols = min(COLS, Q - q0);            // this workgroup's source / output columns
   const int li = lane & 31, kk = lane >> 5;
   const float* xi = x + (size_t)b * R * Q;
   float* yi = y + (size_t)b * R * Q;
@@ -217,47 +237,45 @@ __global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restric
     for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
   const int k_lo = max(0, r0 - half) / kBtChunk * kBtChunk, k_hi = min(R, r0 + kBtRows + half);
   const bool vec4 = (Q & 3) == 0 && (ncols & 3) == 0;
-  // chunk loader: 32 rows x ncols floats, row-contiguous in global memory
+  // chunk loader: 32 rows x ncols floats, row-contiguous in global memory; NW*8 float4 slots per row, 4 per thread
   float4 g[4];
   auto gload = [&](int kc) {
     if (vec4) {
       const int nq4 = ncols >> 2;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int e = tid + i * 256, rr = e / 32, c4 = e - rr * 32;            // 32 float4 slots per row (128 columns)
+        const int e = tid + i * NTH, rr = e / (NW * 8), c4 = e - rr * (NW * 8);
         const int k = kc + rr;
-        g[i] = (rr < kBtChunk && c4 < nq4 && k < R) ? *reinterpret_cast<const float4*>(xi + (size_t)k * Q + q0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        g[i] = (c4 < nq4 && k < R) ? *reinterpret_cast<const float4*>(xi + (size_t)k * Q + q0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
       }
     }
   };
   auto lstore = [&](int buf, int kc) {
-    float* d = Bs + buf * kBtChunk * kBtStride;
+    float* d = Bs + buf * kBtChunk * STRIDE;
     if (vec4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int e = tid + i * 256, rr = e / 32, c4 = e - rr * 32;
-        if (rr < kBtChunk) *reinterpret_cast<float4*>(d + rr * kBtStride + 4 * c4) = g[i];
+        const int e = tid + i * NTH, rr = e / (NW * 8), c4 = e - rr * (NW * 8);
+        *reinterpret_cast<float4*>(d + rr * STRIDE + 4 * c4) = g[i];
       }
     } else {
-      for (int e = tid; e < kBtChunk * 128; e += 256) {
-        const int rr = e >> 7, c = e & 127;
+      for (int e = tid; e < kBtChunk * COLS; e += NTH) {
+        const int rr = e / COLS, c = e - rr * COLS;
         const int k = kc + rr;
-        d[rr * kBtStride + c] = (c < ncols && k < R) ? xi[(size_t)k * Q + q0 + c] : 0.f;
+        d[rr * STRIDE + c] = (c < ncols && k < R) ? xi[(size_t)k * Q + q0 + c] : 0.f;
       }
     }
   };
   gload(k_lo);
   lstore(0, k_lo);
   __syncthreads();
-  // wave w owns column tile w of the workgroup (NQ columns) for all four 32-row blocks: every wave has the same band structure,
-  // so no wave idles at the chunk barriers while another works through its band
   const float* ta0 = tz + kBtPad + half - (r0 + li) + kk;     // + k - 32*jb
   int buf = 0;
   for (int kc = k_lo; kc < k_hi; kc += kBtChunk, buf ^= 1) {
     const bool more = kc + kBtChunk < k_hi;
     if (more) gload(kc + kBtChunk);                            // next chunk's loads fly under this chunk's MFMAs
     {
-      const float* bb = Bs + buf * kBtChunk * kBtStride + kk * kBtStride + wave * NQ + li;
+      const float* bb = Bs + buf * kBtChunk * STRIDE + kk * STRIDE + wave * 32 + li;
 #pragma unroll
       for (int jb = 0; jb < 4; ++jb) {
         // the k-pairs of this chunk inside the band of row block jb (rows r0 + 32*jb - half .. r0 + 32*jb + 31 + half)
@@ -265,50 +283,74 @@ __global__ __launch_bounds__(256) void blur_band_t_kernel(const float* __restric
         const int kp_lo = max(0, (lo - kc) >> 1), kp_hi = min(kBtChunk / 2, (hi - kc + 1) >> 1);
         if (r0 + 32 * jb >= R) continue;
         const float* ta = ta0 - 32 * jb + kc;
-        for (int kp = kp_lo; kp < kp_hi; ++kp)
-          acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[2 * kp], bb[2 * kp * kBtStride], acc[jb], 0, 0, 0);
+        // groups of 4 k-pairs, software-pipelined: the 8 operand reads of group g+1 are issued before the 4 MFMAs of group g
+        // (256 cycles of matrix work), so the pipe never waits on an LDS round trip inside a band
+        int kp = kp_lo;
+        const int n4 = (kp_hi - kp_lo) >> 2;
+        if (n4 > 0) {
+          float av[4], bv[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { av[u] = ta[2 * (kp + u)]; bv[u] = bb[2 * (kp + u) * STRIDE]; }
+          for (int gq = 0; gq < n4; ++gq) {
+            float an[4], bn[4];
+            const int kn = gq + 1 < n4 ? kp + 4 : kp;         // last group: re-read itself (harmless) instead of branching
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { an[u] = ta[2 * (kn + u)]; bn[u] = bb[2 * (kn + u) * STRIDE]; }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc[jb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
+            kp += 4;
+          }
+        }
+        for (; kp < kp_hi; ++kp)
+          acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[2 * kp], bb[2 * kp * STRIDE], acc[jb], 0, 0, 0);
       }
     }
     if (more) lstore(buf ^ 1, kc + kBtChunk);
     __syncthreads();
   }
-  // transposed store: tile element (r, q = pixel*C + c) -> out[(pixel*R + r)*C + c]; through this wave's LDS tile (the chunk
-  // buffers are free after the last barrier) so that the 32*C floats of one pixel column leave contiguously
-  constexpr int RUN = 32 * C + 4;                              // one pixel column of the transposed tile (32 rows x C) + pad
-  constexpr int TSZ = PX * RUN > 32 * 33 ? PX * RUN : 32 * 33; // per-wave transpose area, the same for both layouts below
-  static_assert(4 * TSZ <= 2 * kBtChunk * kBtStride, "transpose tiles must fit the chunk buffers");
-  const int sp0 = s0 + wave * PX;                              // first pixel column of this wave's tile
+  // transposed store, one 32-row block of the whole workgroup at a time: tile element (r, q) with q = px*C + c goes to
+  // TT[px][r*C + c] in LDS (the chunk buffers are free after the last barrier), so that the 32*C floats of one pixel column
+  // leave contiguously as float4:  out[(px*R + r)*C + c]
+  float* tt = Bs;
+  const int col = wave * 32 + li;                              // this lane's column inside the workgroup span
+  const int px_l = col / C, c_l = col - px_l * C;
 #pragma unroll
   for (int jb = 0; jb < 4; ++jb) {
     const int rw0 = r0 + 32 * jb;
-    if (rw0 >= R) break;
+    if (rw0 >= R) break;                                       // uniform over the workgroup
     const int nrow = min(32, R - rw0);
-    if (nrow == 32 && ((R * C) & 3) == 0) {
-      // tile element (r, px, c) -> tt[px][r*C + c]: a pixel column is 32*C contiguous floats in the output, read back as float4
-      float* tt = Bs + wave * TSZ;
-      const int px_l = li / C, c_l = li - px_l * C;
-      if (li < NQ) {
+    if (jb) __syncthreads();                                   // the previous block has been read out
 #pragma unroll
-        for (int q = 0; q < 16; ++q) tt[px_l * RUN + ((q & 3) + 8 * (q >> 2) + 4 * kk) * C + c_l] = acc[jb][q];
-      }
-      // same wave writes and reads: LDS executes a wave's operations in order
-      for (int f = lane; f < PX * 8 * C; f += 64) {
+    for (int q = 0; q < 16; ++q) tt[px_l * RUN + ((q & 3) + 8 * (q >> 2) + 4 * kk) * C + c_l] = acc[jb][q];
+    __syncthreads();
+    if (nrow == 32 && ((R * C) & 3) == 0) {
+      for (int f = tid; f < PXW * 8 * C; f += NTH) {
         const int px = f / (8 * C), w4 = f - px * 8 * C;
-        const int sp = sp0 + px;
+        const int sp = s0 + px;
         if (sp < S) *reinterpret_cast<float4*>(yi + ((size_t)sp * R + rw0) * C + 4 * w4) = *reinterpret_cast<const float4*>(tt + px * RUN + 4 * w4);
       }
     } else {
-      float* tt = Bs + wave * TSZ;
-#pragma unroll
-      for (int q = 0; q < 16; ++q) tt[((q & 3) + 8 * (q >> 2) + 4 * kk) * 33 + li] = acc[jb][q];
-      for (int e = lane; e < PX * 32 * C; e += 64) {
+      for (int e = tid; e < PXW * 32 * C; e += NTH) {
         const int px = e / (32 * C), rem = e - px * 32 * C;
-        const int r = rem / C, c = rem - r * C;
-        const int sp = sp0 + px;
-        if (sp < S && r < nrow) yi[((size_t)sp * R + rw0 + r) * C + c] = tt[r * 33 + px * C + c];
+        const int r = rem / C;
+        const int sp = s0 + px;
+        if (sp < S && r < nrow) yi[((size_t)sp * R + rw0) * C + rem] = tt[px * RUN + rem];
       }
     }
   }
+}
+
+template <int C>
+void launch_band_t(hipStream_t s, const float* src, float* dst, int B, int R, int S, const float* taps, int T) {
+  using G = BandCfg<C>;
+  const int cgs = (int)bg::cdiv(S, G::PXW), rgs = (int)bg::cdiv(R, kBtRows);
+  const size_t lds = ((size_t)((T + 2 * kBtPad + 3) & ~3) + G::BUF) * sizeof(float);
+  auto kern = blur_band_t_kernel<C>;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * rgs * cgs)), dim3(G::NTH), lds, s, src, dst, R, S, rgs, cgs, taps, T);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -375,18 +417,8 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const float* __restrict
   float* Y = sl + 32 * XS;                                    // [RB*16][YS] W-passed rows, circular
   const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, kk = lane >> 4;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifndef BLUR_STRIP_PRIO
-#define BLUR_STRIP_PRIO 2
-#endif
-#if BLUR_STRIP_PRIO == 1
-  if (__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 4) & 1) __builtin_amdgcn_s_setprio(1);       // HW_ID[3:0]: odd wave slot
-#elif BLUR_STRIP_PRIO == 2
-  // Two workgroups share a CU, so two waves running this same program share each SIMD's matrix pipe.  Contending MFMA by MFMA
-  // they fall into lockstep (both in a chain, then both in loads / stores / barriers): the pipe is contended half of the time
-  // and idle the rest.  A static priority for the workgroup that sits SECOND in the CU's LDS (LDS_ALLOC.LDS_BASE != 0) lets
-  // its chains run as if alone; the other's chains then fall into its memory phases.
-  if (__builtin_amdgcn_s_getreg((7 << 11) | (0 << 6) | 6) != 0) __builtin_amdgcn_s_setprio(1);
-#endif
+  // (Measured and dropped: a static s_setprio for one of the two co-resident workgroups -- by hardware wave slot or by LDS base --
+  // and a start stagger between them: neither moves the kernel time, profiles/r02_b_blur_notes.md.)
   // blocks b, b+8, b+16, ... share an XCD (round-robin dispatch): the strips of one image are consecutive there and re-use each
   // other's halo columns from that L2 (speed only)
   const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
@@ -684,14 +716,6 @@ int launch_strip(dim3 grid, hipStream_t s, const float* x, float* y, int B, int 
     if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "blur_strip: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr = true;
   }
-#ifndef BLUR_STRIP_LDS_PAD
-#define BLUR_STRIP_LDS_PAD 1
-#endif
-#if BLUR_STRIP_LDS_PAD
-  // never three workgroups on one CU while another holds one: a grid of two rounds would run as 3 + 1 on some CU pairs and
-  // the launch would last as long as the triple (the footprint is just under a third of the 160 KiB)
-  if (3 * lds <= 160 * 1024) lds = 160 * 1024 / 3 + 1024;
-#endif
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, y, B, H, W, strips, taps, T STRIP_DBG_ARG);
   return BG_OK;
 }
@@ -841,20 +865,16 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
     // measured (64 x 256x256x3): 31 / 143 / 255 taps 0.075 / 0.126 / 0.160 ms against 0.17 / 0.47 / 0.67 for the line kernels;
     // 128 x 128x128x3 at 31 taps 0.043 against 0.068.
     if (path == 2) {
-      const int PX = 32 / C;
-      const size_t lds_t = ((size_t)((n_taps + 2 * kBtPad + 3) & ~3) + 2 * kBtChunk * kBtStride) * sizeof(float);
       for (int pass = 0; pass < 2; ++pass) {
         const int R = pass == 0 ? H : W, S = pass == 0 ? W : H;
-        const int cg = (int)bg::cdiv(S, 4 * PX), rgs = (int)bg::cdiv(R, kBtRows);
         bg::Launch L(stream, pass == 0 ? "blur_band_t1" : "blur_band_t2", flops / 2, bytes);
-        const dim3 grid((unsigned)((size_t)B * rgs * cg));
         const float* src = pass == 0 ? x : tmp_d;
         float* dst = pass == 0 ? tmp_d : y;
         switch (C) {
-          case 1: hipLaunchKernelGGL(blur_band_t_kernel<1>, grid, dim3(256), lds_t, s, src, dst, R, S, rgs, cg, taps_d, n_taps); break;
-          case 2: hipLaunchKernelGGL(blur_band_t_kernel<2>, grid, dim3(256), lds_t, s, src, dst, R, S, rgs, cg, taps_d, n_taps); break;
-          case 3: hipLaunchKernelGGL(blur_band_t_kernel<3>, grid, dim3(256), lds_t, s, src, dst, R, S, rgs, cg, taps_d, n_taps); break;
-          default: hipLaunchKernelGGL(blur_band_t_kernel<4>, grid, dim3(256), lds_t, s, src, dst, R, S, rgs, cg, taps_d, n_taps); break;
+          case 1: launch_band_t<1>(s, src, dst, B, R, S, taps_d, n_taps); break;
+          case 2: launch_band_t<2>(s, src, dst, B, R, S, taps_d, n_taps); break;
+          case 3: launch_band_t<3>(s, src, dst, B, R, S, taps_d, n_taps); break;
+          default: launch_band_t<4>(s, src, dst, B, R, S, taps_d, n_taps); break;
         }
         int rc = L.done("blur_band_t_kernel");
         if (rc) return rc;

@@ -157,8 +157,11 @@ def test_celeba64_batch256_step_matches_oracle():
     # atol 4e-4 of the variable's largest entry, twice the batch-64 figure (measured worst case here: 2.2e-4)
     for a, b in zip(product_grads(gan.discriminator), oracle_grad_list(dg)):
         np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=4e-4 * max(np.abs(b).max(), 1e-6))
+    # generator: gradients of 5e-5 left over from the BatchNorm-backward cancellation (see test_gradients_match_oracle); at this
+    # batch 2 of 6.5 M elements of one kernel sit at 1.3e-2 of the variable's maximum -- the float32 ORACLE is 1.4e-2 off
+    # its own float64 run already at batch 64
     for a, b in zip(product_grads(gan.generator), oracle_grad_list(gg)):
-        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=1e-2 * max(np.abs(b).max(), 1e-6))
+        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=2e-2 * max(np.abs(b).max(), 1e-6))
     np.testing.assert_allclose(gan.images[0].cpu().numpy(), fakes, rtol=1e-4, atol=1e-5)
     for k in ("real_scores", "disc_loss", "gp_term", "norm_term"):
         assert abs(got[k] - met[k]) < 1e-4 * max(1, abs(met[k])), (k, got[k], met[k])

@@ -20,7 +20,7 @@ def main():
             for r in csv.DictReader(open(f)):
                 if pat not in r["Kernel_Name"]:
                     continue
-                k = (r["Kernel_Name"].split("(")[0], r["Counter_Name"])
+                k = (r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0], r["Counter_Name"])
                 per.setdefault(k, {}).setdefault(int(r["Dispatch_Id"]), 0.0)
                 per[k][int(r["Dispatch_Id"])] += float(r["Counter_Value"])
             for (kn, cn), dv in per.items():
