@@ -76,18 +76,34 @@ def cpu_baseline(arch, batch, sigma, seconds_budget=30.0):
                       f"{torch.get_num_threads()} threads, autograd double backward for the penalty)"}
 
 
+TRAFFIC_FILE = "profiles/r02_hbm_traffic.json"
+
+
 def hbm_traffic(kernel, arch, batch):
-    """HBM-side bytes per launch of the dominant kernel from the committed PMC passes (tools/pmc_traffic.py over this very
-    command, separate --pmc runs as MI355X_MICROARCH.md prescribes); None when no profile exists for the workload."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_k_hbm_traffic.json")
+    """HBM-side bytes per launch of ``kernel`` from the committed PMC passes (tools/pmc_step.sh / tools/pmc_blur.sh over this
+    very workload: separate --pmc runs as MI355X_MICROARCH.md prescribes; the counters cannot be read live).  None when no
+    profile exists for the workload OR the kernel sources have changed since it was taken (the entry carries their hash)."""
+    import hashlib
+    root = os.path.dirname(os.path.abspath(__file__))
     try:
-        with open(path) as f:
+        with open(os.path.join(root, TRAFFIC_FILE)) as f:
             d = json.load(f)
     except OSError:
         return None
-    if d.get("arch") != arch or d.get("batch") != batch or kernel not in d.get("kernels", {}):
-        return None
-    return round(d["kernels"][kernel]["hbm_bytes_per_launch"])
+    for e in d.get("entries", []):
+        if e.get("arch") != arch or e.get("batch") != batch or kernel not in e.get("kernels", {}):
+            continue
+        h = hashlib.sha1()
+        try:
+            for src in e["sources"]:
+                with open(os.path.join(root, src), "rb") as f:
+                    h.update(f.read())
+        except OSError:
+            return None
+        if h.hexdigest()[:16] != e.get("sources_sha"):
+            return None                     # stale: the kernel was edited after the profile was taken
+        return round(e["kernels"][kernel]["hbm_bytes_per_launch"])
+    return None
 
 
 def bench_blur(args):
@@ -259,7 +275,7 @@ def main():
                     # zero-padding taps that position-major tiles skip -- how busy the matrix pipe is, not how useful
                     "executed": {"achieved": round(ach_x, 3), "frac": round(ach_x / PEAK_MFMA_F32_TFLOPS, 4)},
                     "traffic": traffic,
-                    "traffic_unit": "HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_k_hbm_traffic.json)" if traffic else None,
+                    "traffic_unit": f"HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, {TRAFFIC_FILE})" if traffic else None,
                     "algorithmic_bytes_per_launch": round(by / cnt) if by else None,
                     "launches_per_step": cnt // nprof, "avg_launch_ms": round(ms / cnt, 5),
                     "all_mfma_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 3),

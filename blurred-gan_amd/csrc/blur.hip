@@ -406,6 +406,238 @@ struct StripCfg {
 #define STRIP_DBG_ARG
 #endif
 
+// ------------------------------------------------------------------------------------------------
+// Up to 33 taps (band reach P <= 16): every WAVE is an autonomous pipeline -- no workgroup barrier, no shared tile.
+// A wave owns a column strip of 16 output pixels (3 channels) or 48 (1 channel) of one image segment and walks down it in
+// blocks of 16 rows; per block:
+//   W pass   X block (16 rows x (16*TPW + 32) pixels, the wave's PRIVATE slice of LDS) -> Y block, one accumulator per plane
+//            (plane = channel for RGB, 16-pixel tile for grey);
+//   4x4 transpose between lane groups and registers (a 1 KB wave-private LDS tile per plane): an accumulator holds rows 4g+i of its
+//            column in register i of lane group g; as a contraction operand the next pass wants row 4s+g in register s.  After it
+//            the last three Y blocks simply stay in registers: no ring in LDS, nothing shared between waves;
+//   H pass   output block b-1 from Y blocks b-2, b-1, b, computed transposed (Y as the row operand, Toeplitz as the column
+//            operand): a lane ends with 4 consecutive pixels of one row -- all their channels = 12 contiguous floats for RGB;
+//   the next X block's global loads are issued before the W pass and written to LDS after the H pass (in-order LDS, same wave).
+// With no barriers the waves of a CU drift apart by themselves: one wave's loads, LDS traffic and stores run under another's
+// MFMA chains.  Halo rows at a segment boundary cost one extra W pass each side; halo columns are re-read from the XCD's L2
+// (48 pixels in for 16 out) -- HBM sees each byte once.
+// ------------------------------------------------------------------------------------------------
+template <int C, int P>
+struct ColsCfg {
+  static constexpr int TPW = C == 3 ? 1 : 3;                  // 16-pixel tiles per wave
+  static constexpr int PXO = 16 * TPW;                        // output pixels per wave
+  static constexpr int XW = (PXO + 32) * C;                   // input floats per row: 144 (RGB), 80 (grey)
+  static constexpr int XS = XW + 2;                           // = 2 mod 4, XS/2 odd: operand reads at stride C are conflict-free
+  static constexpr int NK = 4 + P / 2;
+  static constexpr int F4 = XW / 4;
+  static constexpr int NLD = 16 * F4 / 64;                    // float4 per lane per block: 9 (RGB), 5 (grey)
+  static constexpr int TS = 17;                               // row stride of the per-plane transpose tile
+  static constexpr int XBLK = 16 * XS + 3 * 16 * TS;          // per wave: X block + three 16 x 16 transpose tiles
+  static constexpr size_t lds_bytes = ((size_t)4 * XBLK + 128) * sizeof(float);
+  static_assert(C == 1 || C == 3, "planes are channels or tiles");
+  static_assert(P % 4 == 0 && P >= 4 && P <= 16, "band reach within one block either side");
+  static_assert(16 * F4 % 64 == 0, "block loads must divide evenly over a wave");
+};
+
+#ifndef BLUR_COLS_WPS
+#define BLUR_COLS_WPS 3
+#endif
+template <int C, int P>
+__global__ __launch_bounds__(256, BLUR_COLS_WPS) void blur_cols_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int strips,
+                                                        int segs, int seg_rows, const float* __restrict__ taps, int T STRIP_DBG_PARAM) {
+#ifdef BLUR_STRIP_STAMP
+  const unsigned long long t0 = __builtin_amdgcn_s_memtime(), r0 = __builtin_amdgcn_s_memrealtime();
+#endif
+  using K = ColsCfg<C, P>;
+  constexpr int TPW = K::TPW, PXO = K::PXO, XS = K::XS, NK = K::NK, F4 = K::F4, NLD = K::NLD;
+  extern __shared__ __attribute__((aligned(16))) float sl[];
+  const int tid = threadIdx.x, lane = tid & 63, li = lane & 15, g = lane >> 4;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* tz = sl + 4 * K::XBLK;                               // zero-padded taps (see blur_strip_kernel: never straight from global)
+  if (tid < 128) tz[tid] = (tid >= 48 && tid < 48 + T) ? taps[tid - 48] : 0.f;
+  __syncthreads();                                             // the only barrier: before any wave can have left
+  const int half = T >> 1, WC = W * C;
+  float toep[NK];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) toep[j] = tz[4 * j + g - li - P + half + 48];
+  // work unit of this wave: blocks b, b+8, ... share an XCD and walk the units of one image in order (halo columns from L2)
+  const int upi = strips * segs, wpi = (upi + 3) >> 2;
+  const int xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+  const int img = (idx / wpi) * 8 + xcd, unit = (idx - (idx / wpi) * wpi) * 4 + wave;
+  if (img >= B || unit >= upi) return;
+  const int seg = unit / strips, strip = unit - seg * strips;
+  const int p0 = strip * PXO;                                 // first output pixel
+  const int qin0 = (p0 - 16) * C;                             // first input column (may be negative)
+  const int bl = seg * seg_rows >> 4, bh = min((H + 15) >> 4, (seg + 1) * seg_rows >> 4);   // output blocks [bl, bh)
+  float* X = sl + wave * K::XBLK;
+  float* TT = X + 16 * XS;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x + (size_t)img * H * WC), 0, H * WC * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(y + (size_t)img * H * WC, 0, H * WC * 4, 0x00020000);
+  constexpr int kOob = (int)0x80000000;
+  float4 gq[NLD];
+  auto gload = [&](int blk) {                                  // rows / columns outside the image: out-of-range offset -> zeros
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = lane + i * 64, rr = e / F4, c4 = e - rr * F4;
+      const int r = blk * 16 + rr, q = qin0 + 4 * c4;
+      gq[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (r >= 0 && r < H && q >= 0 && q < WC) ? (r * WC + q) * 4 : kOob, 0, 0));
+    }
+  };
+  auto xstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int e = lane + i * 64, rr = e / F4, c4 = e - rr * F4;
+      float2* d = reinterpret_cast<float2*>(X + rr * XS + 4 * c4);
+      d[0] = make_float2(gq[i].x, gq[i].y);
+      d[1] = make_float2(gq[i].z, gq[i].w);
+    }
+  };
+  floatx4 Ya[3], Yb[3], Yc[3];
+#pragma unroll
+  for (int p = 0; p < 3; ++p) Ya[p] = Yb[p] = Yc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+  int b = bl - 1;
+  gload(b);
+  xstore();
+  // one block step; Y2 receives block b, Y0 / Y1 hold blocks b-2 / b-1
+  auto step = [&](floatx4 (&Y0)[3], floatx4 (&Y1)[3], floatx4 (&Y2)[3]) {
+    gload(b + 1);                                              // in flight under this step's MFMAs (past the segment: wasted, harmless)
+    {
+      // operand reads in groups of 4 k-steps, one group ahead of the MFMAs that consume them (all at once costs 12 more live
+      // registers and a wave per SIMD)
+      constexpr int GS = 4, NG = (NK + GS - 1) / GS;
+      const float* xa = X + li * XS + (16 - P + g) * C;
+      float av[2][GS][3];
+      auto rd = [&](int grp, float (&dst)[GS][3]) {
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+          const int j = grp * GS + u;
+          if (j < NK) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) dst[u][p] = C == 3 ? xa[4 * j * C + p] : xa[4 * j + 16 * p];
+          }
+        }
+      };
+      rd(0, av[0]);
+#pragma unroll
+      for (int p = 0; p < 3; ++p) Y2[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int grp = 0; grp < NG; ++grp) {
+        if (grp + 1 < NG) rd(grp + 1, av[(grp + 1) & 1]);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < GS; ++u) {
+          const int j = grp * GS + u;
+          if (j < NK) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) Y2[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[grp & 1][u][p], toep[j], Y2[p], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      // accumulator layout (row 4g+i in register i) -> contraction-operand layout (row 4s+g in register s) through the wave's own
+      // LDS tile: same wave writes and reads, LDS serves a wave's operations in order, no barrier.  (The register-only route,
+      // v_permlane16_swap + v_permlane32_swap, is miscompiled by this hipcc: two swaps of different register pairs are merged
+      // into one -- tools/probes/permlane_swap_miscompile.hip reproduces it.)  The first H-pass k-steps read the two OLDER blocks, so this round
+      // trip hides under them.
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        float* tp = TT + p * 16 * K::TS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) tp[(4 * g + i) * K::TS + li] = Y2[p][i];
+      }
+#pragma unroll
+      for (int p = 0; p < 3; ++p) {
+        const float* tp = TT + p * 16 * K::TS;
+#pragma unroll
+        for (int sI = 0; sI < 4; ++sI) Y2[p][sI] = tp[(4 * sI + g) * K::TS + li];
+      }
+    }
+    const int o = b - 1;
+    if (o >= bl) {                                             // wave-uniform
+      floatx4 acc[3];
+#pragma unroll
+      for (int p = 0; p < 3; ++p) acc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < NK; ++j) {
+        constexpr int dummy = 0; (void)dummy;
+        const int off = 4 * j - P;                             // first row of this k-step relative to the output block (compile time)
+        const int blk = off < 0 ? 0 : (off < 16 ? 1 : 2);      // Y0 / Y1 / Y2
+        const int sib = (off + 16) % 16 / 4;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const float a = blk == 0 ? Y0[p][sib] : (blk == 1 ? Y1[p][sib] : Y2[p][sib]);
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, toep[j], acc[p], 0, 0, 0);
+        }
+      }
+      const int row = 16 * o + li;
+      typedef unsigned u4 __attribute__((__vector_size__(4 * sizeof(unsigned))));
+      if (C == 3) {
+        float v[12];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) v[3 * i + c] = acc[c][i];
+        const int q = (p0 + 4 * g) * 3;                        // 4 consecutive pixels, all channels: 12 contiguous floats
+        const int base = (row < H && p0 + 4 * g < W) ? (row * WC + q) * 4 : kOob;
+#pragma unroll
+        for (int f = 0; f < 3; ++f)
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, make_float4(v[4 * f], v[4 * f + 1], v[4 * f + 2], v[4 * f + 3])), rsy,
+                                                 base == kOob ? kOob : base + 16 * f, 0, 0);
+      } else {
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+          const int q = p0 + 16 * p + 4 * g;
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc[p]), rsy, (row < H && q < W) ? (row * WC + q) * 4 : kOob, 0, 0);
+        }
+      }
+    }
+    xstore();                                                  // block b+1 replaces block b (every read of b has been issued)
+    ++b;
+  };
+  // the two older blocks move down by register copies (24 v_mov per 72 MFMAs): one step body instead of three rotated ones
+  // keeps the kernel under the register budget of three waves per SIMD
+  for (; b <= bh;) {
+    step(Ya, Yb, Yc);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { Ya[p] = Yb[p]; Yb[p] = Yc[p]; }
+  }
+#ifdef BLUR_STRIP_STAMP
+  if (lane == 0) {                       // shader cycles and 100 MHz reference ticks of this wave's life
+    unsigned long long* d = dbg + ((size_t)blockIdx.x * 4 + wave) * 4;
+    d[0] = t0; d[1] = r0; d[2] = __builtin_amdgcn_s_memtime(); d[3] = __builtin_amdgcn_s_memrealtime();
+  }
+#endif
+}
+
+template <int C, int P>
+int launch_cols(hipStream_t s, const float* x, float* y, int B, int H, int W, const float* taps, int T, void* dbg_) {
+#ifdef BLUR_STRIP_STAMP
+  unsigned long long* dbg = static_cast<unsigned long long*>(dbg_);
+#endif
+  using K = ColsCfg<C, P>;
+  const int strips = (int)bg::cdiv(W, K::PXO);
+  // segments of rows: enough waves for two per SIMD (2048 on 256 CUs; measured best: 1024 / 2048 / 3072 / 4096 waves give
+  // 38.6 / 35.9 / 37.0 / 41.1 us on 64 x 256x256x3 -- a segment boundary costs two extra W passes per wave), each segment at
+  // least 32 rows
+  static const int want = getenv("BG_BLUR_COLS_WAVES") ? atoi(getenv("BG_BLUR_COLS_WAVES")) : 2048;
+  int segs = (int)std::min<long>(std::max<long>(1, bg::cdiv(want, (size_t)B * strips)), std::max(1, H / 32));
+  const int seg_rows = (int)bg::cdiv(bg::cdiv(H, segs), 16) * 16;
+  segs = (int)bg::cdiv(H, seg_rows);
+  const int wpi = (strips * segs + 3) / 4;
+  const dim3 grid((unsigned)(8 * bg::cdiv(B, 8) * wpi));
+  auto kern = blur_cols_kernel<C, P>;
+  const size_t lds = K::lds_bytes;
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, y, B, H, W, strips, segs, seg_rows, taps, T STRIP_DBG_ARG);
+  return BG_OK;
+}
+
+template <int C>
+int launch_cols_c(int reach, hipStream_t s, const float* x, float* y, int B, int H, int W, const float* taps, int T, void* dbg) {
+  if (reach <= 4) return launch_cols<C, 4>(s, x, y, B, H, W, taps, T, dbg);
+  if (reach <= 8) return launch_cols<C, 8>(s, x, y, B, H, W, taps, T, dbg);
+  return launch_cols<C, 16>(s, x, y, B, H, W, taps, T, dbg);
+}
+
 template <int C, int P>
 __global__ __launch_bounds__(256) void blur_strip_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W, int strips,
                                                          const float* __restrict__ taps, int T STRIP_DBG_PARAM) {
@@ -838,6 +1070,13 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   if (path == 4) {
     const int strips = (int)bg::cdiv(W, kSP);
     const dim3 grid((unsigned)(8 * bg::cdiv(B, 8) * strips));
+    static const int no_cols = getenv("BG_BLUR_NO_COLS") ? 1 : 0;
+    if ((n_taps >> 1) <= 16 && !no_cols && (size_t)H * W * C < (1u << 29)) {
+      bg::Launch L(stream, "blur_cols", flops, bytes);
+      const int rc = C == 3 ? launch_cols_c<3>(n_taps >> 1, s, x, y, B, H, W, taps_d, n_taps, tmp_d) : launch_cols_c<1>(n_taps >> 1, s, x, y, B, H, W, taps_d, n_taps, tmp_d);
+      if (rc) return rc;
+      return L.done("blur_cols_kernel");
+    }
     bg::Launch L(stream, "blur_strip", flops, bytes);
     const int rc = C == 3 ? launch_strip_c<3>(n_taps >> 1, grid, s, x, y, B, H, W, strips, taps_d, n_taps, tmp_d)
                           : launch_strip_c<1>(n_taps >> 1, grid, s, x, y, B, H, W, strips, taps_d, n_taps, tmp_d);

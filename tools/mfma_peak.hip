@@ -159,6 +159,9 @@ int main() {
       4.0 * 8 * 4 * 2.0 * 16 * 16 * 4, 1024, iters / 4);
   run("16x16x4 f32 RANDOM, 8 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma16_rand_loop<8>, dim3(g), dim3(256), 0, 0, out, it); },
       4.0 * 8 * 8 * 2.0 * 16 * 16 * 4, 1024, iters / 8);
+  for (int wgs : {256, 512, 1024})
+    run("16x16x4 f32 RANDOM, 3 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma16_rand_loop<3>, dim3(g), dim3(256), 0, 0, out, it); },
+        4.0 * 8 * 3 * 2.0 * 16 * 16 * 4, wgs, iters / 3);
   run("32x32x16 bf16 RANDOM, 4 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma_bf16_rand_loop<4>, dim3(g), dim3(256), 0, 0, out, it); },
       4.0 * 4 * 4 * 2.0 * 32 * 32 * 16, 1024, iters);
   run("32x32x16 bf16 RANDOM, 1 acc", [&](int g, int it) { hipLaunchKernelGGL(mfma_bf16_rand_loop<1>, dim3(g), dim3(256), 0, 0, out, it); },
