@@ -7,6 +7,8 @@
 
 namespace {
 
+__device__ inline bool bg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
 constexpr int kT = 256;
 
 inline unsigned grid_for(size_t n, int per_thread = 1) {
@@ -115,18 +117,35 @@ __global__ __launch_bounds__(1024) void gemv_t_kernel(const float* __restrict__ 
   }
 }
 
-// N == 1, no transposes: one wave per row (critic's Dense(2048 -> 1))
+// N == 1, no transposes (critic's Dense(2048 -> 1); 6272 -> 1 for MNIST): ONE WORKGROUP per row, float4 loads, every load of a
+// thread independent.  (One wave per row left 192 waves on 256 CUs for the MNIST critic and a 98-deep dependent load / FMA
+// chain per lane: 31 us for 4.8 MB.)
 __global__ __launch_bounds__(kT) void rowdot_kernel(const float* __restrict__ A, const float* __restrict__ w, float* __restrict__ C,
                                                     int M, int K, const float* __restrict__ bias, float beta, float scale) {
-  const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * (kT / 64) + (threadIdx.x >> 6);
-  if (row >= M) return;
+  __shared__ float red[kT / 64];
+  const int row = blockIdx.x, tid = threadIdx.x;
   const float* a = A + (size_t)row * K;
   float acc = 0.f;
-  for (int k = lane; k < K; k += 64) acc = fmaf(a[k], w[k], acc);
+  if ((K & 3) == 0 && bg_aligned16(a) && bg_aligned16(w)) {
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* w4 = reinterpret_cast<const float4*>(w);
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    for (int k = tid; k < (K >> 2); k += kT) {
+      const float4 x = a4[k], y = w4[k];
+      p0 = fmaf(x.x, y.x, p0); p1 = fmaf(x.y, y.y, p1); p2 = fmaf(x.z, y.z, p2); p3 = fmaf(x.w, y.w, p3);
+    }
+    acc = (p0 + p1) + (p2 + p3);
+  } else {
+    for (int k = tid; k < K; k += kT) acc = fmaf(a[k], w[k], acc);
+  }
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_down(acc, off, 64);
-  if (lane == 0) {
-    float v = scale * acc;
+  if ((tid & 63) == 0) red[tid >> 6] = acc;
+  __syncthreads();
+  if (tid == 0) {
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < kT / 64; ++i) sum += red[i];
+    float v = scale * sum;
     if (bias) v += bias[0];
     if (beta != 0.f) v += beta * C[row];
     C[row] = v;
@@ -588,7 +607,7 @@ int bg_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, 
   const double flops = 2.0 * M * (double)N * K;
   if (N == 1 && !transA && K >= 64) {
     bg::Launch L(stream, "dense_rowdot", flops, 4.0 * M * K);
-    hipLaunchKernelGGL(rowdot_kernel, dim3(bg::cdiv(M, kT / 64)), dim3(kT), 0, L.s, A, Bm, C, M, K, bias, beta, scale);
+    hipLaunchKernelGGL(rowdot_kernel, dim3(M), dim3(kT), 0, L.s, A, Bm, C, M, K, bias, beta, scale);
     return L.done("rowdot_kernel");
   }
   if (N == 1 && transA && K >= 64) {
