@@ -35,12 +35,15 @@ __global__ __launch_bounds__(kT) void gemm_naive_kernel(const float* __restrict_
   }
 }
 
-// LDS-tiled SGEMM, 64x64 tile, 16-deep steps, 4x4 outputs per thread (generator's Dense(100 -> 8192) and its
-// weight gradient).  Small problem (0.4 GFLOP): the point is coalesced operand reads, not the MFMA.
+// LDS-tiled SGEMM, 64x64 tile, 32-deep steps, 4x4 outputs per thread (generator's Dense(100 -> 8192) and its
+// weight gradient).  Small problem (0.4 GFLOP, K = 100 or the batch): what it waits for is the global -> LDS round trip of
+// every step, so the steps are deep (4 round trips at K = 100 instead of 7) and the NEXT tile's loads are issued before the
+// current tile's FMAs (register staging): 32 / 50 us -> see DESIGN.md section 7.
 __global__ __launch_bounds__(kT) void gemm_tiled_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                         float* __restrict__ C, int M, int N, int K, int transA, int transB,
                                                         const float* __restrict__ bias, float beta, float scale) {
-  __shared__ float As[16][64 + 4], Bs[16][64 + 4];
+  constexpr int KT = 32, NL = 64 * KT / kT;                   // 8 elements per thread per operand tile
+  __shared__ float As[KT][64 + 4], Bs[KT][64 + 4];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
   float acc[4][4];
@@ -48,23 +51,40 @@ __global__ __launch_bounds__(kT) void gemm_tiled_kernel(const float* __restrict_
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
-  for (int k0 = 0; k0 < K; k0 += 16) {
-    // A tile -> As[k][m]; B tile -> Bs[k][n]; 1024 elements each, 4 per thread
+  float ra[NL], rb[NL];
+  auto gload = [&](int k0) {                                  // A tile -> As[k][m]; B tile -> Bs[k][n]; contiguous index fastest
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NL; ++i) {
       const int e = threadIdx.x + i * kT;
       int kk, mm;
-      if (transA) { kk = e >> 6; mm = e & 63; } else { mm = e >> 4; kk = e & 15; }   // contiguous index fastest
+      if (transA) { kk = e >> 6; mm = e & 63; } else { mm = e / KT; kk = e - mm * KT; }
       const int m = m0 + mm, k = k0 + kk;
-      As[kk][mm] = (m < M && k < K) ? (transA ? A[(size_t)k * M + m] : A[(size_t)m * K + k]) : 0.f;
+      ra[i] = (m < M && k < K) ? (transA ? A[(size_t)k * M + m] : A[(size_t)m * K + k]) : 0.f;
       int kb, nn;
-      if (transB) { nn = e >> 4; kb = e & 15; } else { kb = e >> 6; nn = e & 63; }
+      if (transB) { nn = e / KT; kb = e - nn * KT; } else { kb = e >> 6; nn = e & 63; }
       const int n = n0 + nn, k2 = k0 + kb;
-      Bs[kb][nn] = (n < N && k2 < K) ? (transB ? Bm[(size_t)n * K + k2] : Bm[(size_t)k2 * N + n]) : 0.f;
+      rb[i] = (n < N && k2 < K) ? (transB ? Bm[(size_t)n * K + k2] : Bm[(size_t)k2 * N + n]) : 0.f;
     }
-    __syncthreads();
+  };
+  auto lstore = [&]() {
 #pragma unroll
-    for (int kk = 0; kk < 16; ++kk) {
+    for (int i = 0; i < NL; ++i) {
+      const int e = threadIdx.x + i * kT;
+      int kk, mm;
+      if (transA) { kk = e >> 6; mm = e & 63; } else { mm = e / KT; kk = e - mm * KT; }
+      As[kk][mm] = ra[i];
+      int kb, nn;
+      if (transB) { nn = e / KT; kb = e - nn * KT; } else { kb = e >> 6; nn = e & 63; }
+      Bs[kb][nn] = rb[i];
+    }
+  };
+  gload(0);
+  for (int k0 = 0; k0 < K; k0 += KT) {
+    lstore();
+    __syncthreads();
+    if (k0 + KT < K) gload(k0 + KT);                          // in flight under this tile's FMAs
+#pragma unroll
+    for (int kk = 0; kk < KT; ++kk) {
       float a[4], b[4];
 #pragma unroll
       for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
