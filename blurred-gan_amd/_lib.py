@@ -60,6 +60,7 @@ SIGNATURES = {
     "bg_lerp_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "bg_row_norm_f32": (_i, [_p, _p, _i, _i, _p]),
     "bg_gp_seed_f32": (_i, [_p, _p, _f, _p, _i, _i, _p]),
+    "bg_gp_seed_guarded_f32": (_i, [_p, _p, _f, _p, _i, _i, _p]),
     "bg_mul_grad_f32": (_i, [_p, _p, _p, _f, _f, _p, _z, _p]),
     "bg_tanh_bwd_f32": (_i, [_p, _p, _p, _z, _p]),
     "bg_outer_f32": (_i, [_p, _p, _p, _i, _i, _p]),

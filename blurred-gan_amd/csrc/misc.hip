@@ -440,11 +440,14 @@ __global__ __launch_bounds__(1024) void row_norm_kernel(const float* __restrict_
   }
 }
 
+// GUARD = false reproduces the reference: a sample whose input gradient is exactly zero gives (0 - 1) / 0 * 0 = NaN, as
+// tf.norm's gradient does (wgan.py:245).  GUARD = true (build-side switch) takes the subgradient 0 there.
+template <bool GUARD>
 __global__ __launch_bounds__(kT) void gp_seed_kernel(const float* __restrict__ g, const float* __restrict__ norm, float coef,
                                                      float* __restrict__ out, size_t total, int n_per) {
   for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < total; e += (size_t)gridDim.x * kT) {
     const float n = norm[e / n_per];
-    out[e] = coef * ((n - 1.f) / n) * g[e];
+    out[e] = (GUARD && n == 0.f) ? 0.f : coef * ((n - 1.f) / n) * g[e];
   }
 }
 
@@ -845,7 +848,15 @@ int bg_gp_seed_f32(const float* g, const float* norm_b, float coef, float* out, 
   BG_POINTWISE_PROLOGUE("bg_gp_seed_f32", g && norm_b && out, (long)B * n_per);
   const size_t total = (size_t)B * n_per;
   bg::Launch L(stream, "gp_seed", 0, 8.0 * total);
-  hipLaunchKernelGGL(gp_seed_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, g, norm_b, coef, out, total, n_per);
+  hipLaunchKernelGGL(gp_seed_kernel<false>, dim3(grid_for(total)), dim3(kT), 0, L.s, g, norm_b, coef, out, total, n_per);
+  return L.done("gp_seed_kernel");
+}
+
+int bg_gp_seed_guarded_f32(const float* g, const float* norm_b, float coef, float* out, int B, int n_per, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_gp_seed_guarded_f32", g && norm_b && out, (long)B * n_per);
+  const size_t total = (size_t)B * n_per;
+  bg::Launch L(stream, "gp_seed", 0, 8.0 * total);
+  hipLaunchKernelGGL(gp_seed_kernel<true>, dim3(grid_for(total)), dim3(kT), 0, L.s, g, norm_b, coef, out, total, n_per);
   return L.done("gp_seed_kernel");
 }
 

@@ -261,9 +261,10 @@ def row_norm(g, out_b):
     return out_b
 
 
-def gp_seed(g, norm_b, coef, out):
+def gp_seed(g, norm_b, coef, out, zero_norm_guard=False):
     B = g.shape[0]
-    check(_lib.load().bg_gp_seed_f32(_ptr(g), _ptr(norm_b), coef, _ptr(out), B, g.numel() // B, _stream()), "bg_gp_seed_f32")
+    fn = _lib.load().bg_gp_seed_guarded_f32 if zero_norm_guard else _lib.load().bg_gp_seed_f32
+    check(fn(_ptr(g), _ptr(norm_b), coef, _ptr(out), B, g.numel() // B, _stream()), "bg_gp_seed_f32")
     return out
 
 

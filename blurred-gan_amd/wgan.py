@@ -103,7 +103,7 @@ class WGAN:
 
     def __init__(self, generator: Sequential, discriminator: Sequential, hyperparams: "WGAN.HyperParameters",
                  config: TrainingConfig, *args, reproduce_vector_loss_quirk: bool = True, sync_metrics: bool = True,
-                 sync_batchnorm: bool = True, merge_critic_passes: bool = True, **kwargs):
+                 sync_batchnorm: bool = True, merge_critic_passes: bool = True, gp_zero_norm_guard: bool = False, **kwargs):
         self.hparams = hyperparams
         if dist.world_size() > 1 and int(hyperparams.global_batch_size) != int(hyperparams.batch_size) * dist.world_size():
             import warnings
@@ -146,6 +146,9 @@ class WGAN:
         self.sync_batchnorm = sync_batchnorm  # DP: generator BN statistics over the global batch (False = per replica)
         # critic step: [fakes; reals] and x-hat in one 3B-sample forward / backward (False: two passes, as the reference orders them)
         self.merge_critic_passes = merge_critic_passes and not os.environ.get("BGAN_NO_MERGED_CRITIC")
+        # a sample whose critic input-gradient is exactly zero makes the penalty's second-order seed (n-1)/n * g = NaN, in the
+        # reference too (tf.norm's gradient at 0); True takes the subgradient 0 for that sample instead
+        self.gp_zero_norm_guard = gp_zero_norm_guard
         self._rng_seed = get_seed()
         self._rng_off = 0
         self._bufs = {}
@@ -315,7 +318,7 @@ class WGAN:
             norms = ops.row_norm(g, self._buf("gp_norms", (B,)))
             ops.wgangp_d_loss(fs, rs, norms, inv_gbs, gp_c, e_d, vs, ds3[:B], ds3[B:2 * B], met)    # same seeds, full metrics
             coef = vs * float(hp.gp_coefficient) * 2.0 / float(B * dist.world_size())
-            gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)))
+            gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)), self.gp_zero_norm_guard)
             v0 = D.apply_blur(gbar, self._buf("v0", tuple(g.shape))) if D.blur is not None else gbar
             D.gp_second_order(c3.rows(2 * B, 3 * B), v0, reducer=red)
         else:
@@ -332,7 +335,7 @@ class WGAN:
             if self.uses_gradient_penalty:
                 # d/dW of vec_scale * gp_coefficient * mean_global((n-1)^2): seed carries the whole factor
                 coef = vs * float(hp.gp_coefficient) * 2.0 / float(B * dist.world_size())
-                gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)))
+                gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)), self.gp_zero_norm_guard)
                 chat = D.context(B, "hat")
                 v0 = D.apply_blur(gbar, self._buf("v0", tuple(g.shape))) if D.blur is not None else gbar
                 D.gp_second_order(chat, v0, reducer=red)

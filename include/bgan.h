@@ -172,6 +172,9 @@ int bg_lerp_f32(const float* r, const float* f, const float* alpha_b, float* xha
 int bg_row_norm_f32(const float* g, float* norm_b, int B, int n_per, void* stream);
 /* second-order seed: out[b,:] = coef * (norm[b]-1)/norm[b] * g[b,:]   (d mean((n-1)^2) / dg) */
 int bg_gp_seed_f32(const float* g, const float* norm_b, float coef, float* out, int B, int n_per, void* stream);
+/* the same with the subgradient 0 for a sample whose norm is exactly 0 (the reference, like tf.norm's gradient at 0, yields NaN
+   there and Adam then spreads it into every weight): build-side switch WGANGP(gp_zero_norm_guard=True), off by default */
+int bg_gp_seed_guarded_f32(const float* g, const float* norm_b, float coef, float* out, int B, int n_per, void* stream);
 /* out = d * (ref > 0 ? 1 : alpha) [* keep ? scale : 0] */
 int bg_mul_grad_f32(const float* d, const float* ref, const uint8_t* keep, float alpha, float scale,
                     float* out, size_t n, void* stream);

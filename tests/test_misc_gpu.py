@@ -179,3 +179,16 @@ def test_separable_batchnorm_pieces_equal_fused():
     ops.bn_bwd_stats(dy, y1, x, M, C, m1, i1, sums, ws)
     ops.bn_bwd_apply(dy, y1, x, dx2, M, M, C, gamma, m1, i1, sums)
     assert torch.equal(dx1, dx2) and torch.equal(db, sums[:C]) and torch.equal(dg, sums[C:])
+
+
+def test_gp_seed_zero_norm_quirk_and_guard():
+    """A sample with an exactly-zero input gradient: the reference formula (n-1)/n * g is NaN there (as tf.norm's gradient at 0);
+    the guarded entry point takes the subgradient 0 for that sample and leaves the others untouched."""
+    from blurred_gan_amd import ops
+    g = torch.randn(3, 40, device="cuda")
+    g[1] = 0.0
+    n = ops.row_norm(g, torch.empty(3, device="cuda"))
+    ref = ops.gp_seed(g, n, 0.5, torch.empty_like(g)).cpu()
+    guarded = ops.gp_seed(g, n, 0.5, torch.empty_like(g), zero_norm_guard=True).cpu()
+    assert torch.isnan(ref[1]).all() and torch.isfinite(ref[[0, 2]]).all()
+    assert (guarded[1] == 0).all() and torch.equal(guarded[[0, 2]], ref[[0, 2]])

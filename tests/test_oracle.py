@@ -280,3 +280,22 @@ def test_input_pipeline_resize_matches_torch_half_pixel_bilinear():
         np.testing.assert_allclose(got, ref, atol=1e-12)
     same = O.normalize_resize_bilinear(img, (21, 17))
     np.testing.assert_allclose(same, (img.astype(np.float64) - 127.5) / 127.5, atol=1e-14)      # identity size: normalise only
+
+
+def test_same_padding_rule_agrees_with_an_independent_port_of_keras():
+    """Corroboration (not a pin) of one [TF-knowledge] item.  Keras' `imagenet_utils.correct_pad` -- the padding Keras itself puts
+    in front of a 'valid' stride-2 conv to reproduce TF's SAME geometry -- survives, ported to PyTorch, in the installed
+    `transformers` package (EfficientNet).  For even inputs and stride 2 it must equal the oracle's SAME rule (before = total // 2:
+    1 / 2 for k = 5, 0 / 1 for k = 3), for stride 1 the symmetric k // 2."""
+    try:
+        from transformers.models.efficientnet.modeling_efficientnet import correct_pad
+    except Exception as e:                                     # pragma: no cover
+        pytest.skip(f"transformers' EfficientNet port not importable: {e}")
+    for k in (3, 5, 7):
+        left, right, top, bottom = correct_pad(k, adjust=True)
+        for n in (8, 28, 64, 128):                             # even inputs, as every feature map of the reference models
+            out, before, after = O.same_pads(n, k, 2)
+            assert out == n // 2 and (before, after) == (left, right) == (top, bottom), (k, n, before, after, left, right)
+        left, right, top, bottom = correct_pad(k, adjust=False)
+        out, before, after = O.same_pads(64, k, 1)
+        assert out == 64 and (before, after) == (left, right) == (top, bottom)
