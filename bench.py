@@ -39,6 +39,22 @@ def build_gan(arch, B, world, sigma):
     return gan
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; the contract is ONE JSON line there.  File
+    descriptor 1 points at stderr while the process group (and its first collective, which is what creates the
+    communicator) comes up."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 def cpu_model():
     try:
         with open("/proc/cpuinfo") as f:
@@ -113,8 +129,10 @@ def bench_blur(args):
     reasonable sigma, gaussian_blur.py:15-18).  value = algorithmic GB/s, 8*H*W*C bytes per image per application
     (SURVEY.md 8d), over the whole timed region; roofline = the same figure over the kernels' own HIP-event durations."""
     from blurred_gan_amd import dist, ops
-    world = dist.init_from_env()
-    torch.cuda.set_device(dist.local_rank())
+    with stdout_to_stderr():
+        world = dist.init_from_env()
+        torch.cuda.set_device(dist.local_rank())
+        dist.barrier()
     B, H, W, C = args.batch or 64, 256, 256, 3
     apps = 7
     g = torch.Generator(device="cuda").manual_seed(123123 + dist.rank())
@@ -207,10 +225,14 @@ def main():
     if args.arch == "blur256":
         return bench_blur(args)
     from blurred_gan_amd import dist, ops, callbacks
-    world = dist.init_from_env()
-    assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
-    torch.cuda.set_device(dist.local_rank())
+    with stdout_to_stderr():
+        world = dist.init_from_env()
+        torch.cuda.set_device(dist.local_rank())
+        dist.barrier()                                    # first collective: the communicator (and its banner) is created here
+        if dist.is_initialized():
+            dist.max_over_ranks(0.0)
+    assert world == args.gpus or (world == 1 and args.gpus == 1), f"--gpus {args.gpus} but WORLD_SIZE={world}"
     B = args.batch or {"celeba64": 256, "celeba128": 128, "mnist": 64}[args.arch]
     if args.strong:
         gb = 2048 if args.batch is None else args.batch

@@ -57,6 +57,7 @@ SIGNATURES = {
     "bg_bn_apply_f32": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _f, _p]),
     "bg_bn_bwd_stats_f32": (_i, [_p, _p, _p, _i, _i, _p, _p, _f, _p, _p, _z, _p]),
     "bg_bn_bwd_apply_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _f, _p]),
+    "bg_bn_param_grads_f32": (_i, [_p, _i, _f, _p, _p, _p]),
     "bg_lerp_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "bg_row_norm_f32": (_i, [_p, _p, _i, _i, _p]),
     "bg_gp_seed_f32": (_i, [_p, _p, _f, _p, _i, _i, _p]),

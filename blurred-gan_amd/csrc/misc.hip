@@ -406,6 +406,16 @@ __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(const float* __restric
   }
 }
 
+// dgamma = scale * sums[C + c], dbeta = scale * sums[c]: the parameter gradients of a SyncBN layer out of the (already global)
+// backward sums, pre-divided by the replica count so that the SUM all-reduce of the flat gradient buffer restores them
+__global__ __launch_bounds__(kT) void bn_param_grads_kernel(const float* __restrict__ sums, int C, float scale, float* __restrict__ dgamma,
+                                                            float* __restrict__ dbeta) {
+  const int c = blockIdx.x * kT + threadIdx.x;
+  if (c >= C) return;
+  dbeta[c] = scale * sums[c];
+  dgamma[c] = scale * sums[C + c];
+}
+
 // ---------------------------------------------------------------- pointwise
 __global__ __launch_bounds__(kT) void lerp_kernel(const float* __restrict__ r, const float* __restrict__ f, const float* __restrict__ alpha,
                                                   float* __restrict__ out, size_t total, int n_per) {
@@ -827,6 +837,14 @@ int bg_bn_bwd_apply_f32(const float* dy, const float* y, const float* x, float* 
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M_total, C, gamma, save_mean, save_inv,
                      sums_d + C /* dgamma = sum dz*xhat */, sums_d /* dbeta = sum dz */, lrelu_alpha);
   return L.done("bn_bwd_apply_kernel");
+}
+
+int bg_bn_param_grads_f32(const float* sums_d, int C, float scale, float* dgamma, float* dbeta, void* stream) {
+  BG_REQUIRE(sums_d && dgamma && dbeta, BG_ERR_NULL, "bg_bn_param_grads_f32: null pointer");
+  BG_REQUIRE(C > 0, BG_ERR_BAD_SHAPE, "bg_bn_param_grads_f32: C=%d", C);
+  bg::Launch L(stream, "bn_param_grads", 0, 0);
+  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, sums_d, C, scale, dgamma, dbeta);
+  return L.done("bn_param_grads_kernel");
 }
 
 int bg_lerp_f32(const float* r, const float* f, const float* alpha_b, float* xhat, int B, int n_per, void* stream) {

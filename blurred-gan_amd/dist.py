@@ -265,7 +265,7 @@ def broadcast_object(obj, src=0):
 
 
 def barrier():
-    if world_size() > 1:
+    if collectives_active():          # also in the one-rank rehearsal: its first collective is what creates the communicator
         _quiesce_abi()
         td.barrier()
 

@@ -382,10 +382,7 @@ class Net:
                     ops.bn_bwd_apply(gv, ctx.a[i], ctx.z[i], dz, M, M * world, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], sums,
                                      lrelu_alpha=st.alpha)
                     if need_dw:     # the sums are already global: pre-divide so the flat gradient SUM all-reduce restores them
-                        db.copy_(sums[:C])
-                        dg.copy_(sums[C:])
-                        ops.scale_(db, 1.0 / world)
-                        ops.scale_(dg, 1.0 / world)
+                        ops.bn_param_grads(sums, C, 1.0 / world, dg, db)
                 else:
                     ops.bn_train_bwd(gv, ctx.a[i], ctx.z[i], dz, M, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], dg, db, ws,
                                      lrelu_alpha=st.alpha)

@@ -247,6 +247,10 @@ def bn_bwd_apply(dy, y, x, dx, M, M_total, Cc, gamma, save_mean, save_inv, sums,
     return dx
 
 
+def bn_param_grads(sums, Cc, scale, dgamma, dbeta):
+    check(_lib.load().bg_bn_param_grads_f32(_ptr(sums), Cc, scale, _ptr(dgamma), _ptr(dbeta), _stream()), "bg_bn_param_grads_f32")
+
+
 # ------------------------------------------------------------------ pointwise / losses / adam / rng
 def lerp(r, f, alpha_b, out):
     B = r.shape[0]

@@ -164,6 +164,9 @@ int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, 
                         const float* save_inv, float lrelu_alpha, float* sums_d, void* ws_d, size_t ws_bytes, void* stream);
 int bg_bn_bwd_apply_f32(const float* dy, const float* y, const float* x, float* dx, int M, int M_total, int C, const float* gamma,
                         const float* save_mean, const float* save_inv, const float* sums_d, float lrelu_alpha, void* stream);
+/* dbeta[c] = scale * sums[c], dgamma[c] = scale * sums[C + c]: gamma / beta gradients out of the all-reduced backward sums
+   (scale = 1 / replicas, so that the SUM all-reduce of the flat gradient buffer restores the global value) */
+int bg_bn_param_grads_f32(const float* sums_d, int C, float scale, float* dgamma, float* dbeta, void* stream);
 
 /* ---- pointwise ------------------------------------------------------------------------------ */
 /* wgan.py:239: xhat[b,:] = r[b,:] + alpha[b] * (f[b,:] - r[b,:]) */
