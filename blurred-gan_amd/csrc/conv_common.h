@@ -22,6 +22,8 @@ struct GatherPhase {
   int tap[kMaxTaps];   // (dy+64) | (dx+64)<<8 | wi<<16
 };
 
+extern thread_local int g_conv_stats_rows;   // conv_igemm.hip
+
 struct GatherParams {
   const float* A;      // [B][Hs][Ws][Ck]
   const float* Wt;     // [taps][N][Ck]
@@ -38,6 +40,7 @@ struct GatherParams {
                        // back to back and each phase's tile is stored when its taps are done (short-K transposed convs)
   int ksplit;          // split-K factor of the MFMA kernel (1 = none); partial sums go to slab[split][B*Hd*Wd*N]
   float* slab;
+  float* stats;        // MFMA kernel: per-workgroup column sums / sums of squares of the stored tile, [row][2][N]; null = off
   // epilogue
   int epi_mode;
   const float* bias;

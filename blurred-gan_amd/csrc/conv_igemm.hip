@@ -17,6 +17,10 @@
 #include <cmath>
 #include <cstdlib>
 
+namespace bg {
+thread_local int g_conv_stats_rows = 0;      // rows of bg_epilogue.stats written by this thread's last conv call
+}
+
 namespace {
 
 using bg::GatherParams;
@@ -28,7 +32,10 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // ------------------------------------------------------------------------------------------------
 // MFMA implicit GEMM
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, int BK, int WAVES_M, int WAVES_N>
+// STATS: the variant that also leaves BatchNorm statistics of its tile (bg_epilogue.stats).  A template flag, not a run-time
+// one: the two running sums per accumulator column cost the 64x64 tile its fourth wave per SIMD (103 -> 119 + 16 registers),
+// and the plain variant is the dominant kernel of the step.
+template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool STATS = false>
 __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(const GatherParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;     // 4 or 8 waves per workgroup
   static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
@@ -63,9 +70,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   const int L = p.xcd_swizzle ? bg::xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int n_tile = L / mt, m_tile = L - n_tile * mt;
   const int m0 = m_tile * BM;
-  if (m0 >= Mph) return;
   const int n0 = n_tile * BN;
   const int tid = threadIdx.x;
+  // BatchNorm statistics of the stored tile (bg_epilogue.stats): one partial row per workgroup, [row][2][N]
+  constexpr bool do_stats = STATS;
+  float* stats_row = do_stats ? p.stats + ((size_t)pgrp * mt + m_tile) * 2 * p.N : nullptr;
+  if (m0 >= Mph) {
+    if (do_stats && tid < BN && n0 + tid < p.N) { stats_row[n0 + tid] = 0.f; stats_row[p.N + n0 + tid] = 0.f; }
+    return;
+  }
   const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
 
@@ -237,6 +250,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   // restart from zero for the next phase of the group.  It runs between two K steps: the loads of the next phase's tiles are
   // already in flight and its first fragments already in registers, so only the stores themselves sit between the MFMAs.
   const int col = lane & 31, rhalf = (lane >> 5) * 4;
+  float st_sum[NI], st_sq[NI];                                // column sums of this lane's accumulator columns (do_stats)
+#pragma unroll
+  for (int j = 0; j < NI; ++j) { st_sum[j] = 0.f; st_sq[j] = 0.f; }
   auto epilogue = [&](int q) {
     const int dd = phase_dd[q];
 #pragma unroll
@@ -252,6 +268,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
             const size_t idx = (size_t)(dst + dd) * p.N + n;
             if (p.ksplit > 1) p.slab[(size_t)split * ((size_t)p.B * p.Hd * p.Wd * p.N) + idx] = acc[i][j][r];
             else p.C[idx] = bg::apply_epilogue_pre(p, acc[i][j][r], idx, e_bias[j], e_mul[j]);
+          }
+          if (do_stats) {                                      // rows past M and columns past N hold exact zeros
+            st_sum[j] += acc[i][j][r];
+            st_sq[j] = fmaf(acc[i][j][r], acc[i][j][r], st_sq[j]);
           }
           acc[i][j][r] = 0.f;
         }
@@ -273,6 +293,27 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
     if (--c_left == 0) phase_done();
     step_body(1, [&]() { lstore(0, regA0, regB0); gload(regA0, regB0); });
     if (--c_left == 0) phase_done();
+  }
+  if (do_stats) {
+    // lane halves hold different rows of the same column; waves along M share columns: fixed-order sums through LDS
+    __syncthreads();
+    float* red = smem;                                         // [WAVES_M][BN][2]
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+      const float a = st_sum[j] + __shfl_xor(st_sum[j], 32, 64), b = st_sq[j] + __shfl_xor(st_sq[j], 32, 64);
+      if (lane < 32) {
+        red[(wm * BN + wn * WTN + j * 32 + col) * 2 + 0] = a;
+        red[(wm * BN + wn * WTN + j * 32 + col) * 2 + 1] = b;
+      }
+    }
+    __syncthreads();
+    if (tid < BN && n0 + tid < p.N) {
+      float a = 0.f, b = 0.f;
+#pragma unroll
+      for (int w = 0; w < WAVES_M; ++w) { a += red[(w * BN + tid) * 2]; b += red[(w * BN + tid) * 2 + 1]; }
+      stats_row[n0 + tid] = a;
+      stats_row[p.N + n0 + tid] = b;
+    }
   }
 }
 
@@ -825,9 +866,21 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
   }
   dim3 grid(p.mtiles * bg::cdiv(p.N, BN), 1, (p.nphase / p.pmerge) * ks);
   {
+    // BatchNorm statistics in the epilogue: plain stores only (no split-K slabs, no bias / activation), one row per workgroup
+    const size_t srows = (size_t)(p.nphase / p.pmerge) * p.mtiles;
+    constexpr bool has_stats_variant = (BM == 64 && BN == 64) || (BM == 128 && BN == 32);     // the tiles the default plan picks
+    const bool st_ok = has_stats_variant && epi && epi->stats && ks == 1 && p.epi_mode == BG_EPI_NONE && !p.bias &&
+                       epi->stats_capacity >= srows * 2 * (size_t)p.N;
+    p.stats = st_ok ? epi->stats : nullptr;
+    bg::g_conv_stats_rows = st_ok ? (int)srows : 0;
     bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
     if (L.prof) L.exec_flops(gather_exec_flops(p, BM, BN));
-    hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
+    if constexpr (has_stats_variant) {
+      if (st_ok) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv, true>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
+      else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv, false>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
+    } else {
+      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv, false>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
+    }
     int rc = L.done(name);
     if (rc || ks == 1) return rc;
   }
@@ -861,6 +914,7 @@ int dispatch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const 
 }
 
 int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char* tag) {
+  p.stats = nullptr;
   p.epi_mode = BG_EPI_NONE; p.bias = nullptr; p.ref = nullptr; p.keep = nullptr; p.keep_elems = 0; p.alpha = 0.3f; p.scale = 1.f;
   p.ksplit = 1; p.slab = nullptr;
   if (epi) {
@@ -1011,6 +1065,7 @@ size_t bg_conv2d_splitk_workspace_bytes(int bwd_data, int B, int H, int W, int C
 
 int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int W, int Cin, int Cout, int ksize,
                   int stride, const bg_epilogue* epi, void* stream) {
+  bg::g_conv_stats_rows = 0;
   int rc = check_conv_args("bg_conv2d_fwd", x, wT_d, y, B, H, W, Cin, Cout, ksize, stride);
   if (rc) return rc;
   int taken = 0;
@@ -1029,6 +1084,7 @@ int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int
 
 int bg_conv2d_bwd_data(const float* dy, const float* w_d, float* dx, int B, int H, int W, int Cin, int Cout, int ksize,
                        int stride, const bg_epilogue* epi, void* stream) {
+  bg::g_conv_stats_rows = 0;
   int rc = check_conv_args("bg_conv2d_bwd_data", dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride);
   if (rc) return rc;
   int taken = 0;
@@ -1062,5 +1118,7 @@ int bg_transpose_last2_batched(const float* src_base, float* dst_base, const int
                      reinterpret_cast<const TransposeDesc*>(desc_d), n);
   return L.done("transpose_batched_kernel");
 }
+
+int bg_conv2d_stats_rows(void) { return bg::g_conv_stats_rows; }
 
 }  // extern "C"

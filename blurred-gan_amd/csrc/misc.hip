@@ -714,6 +714,34 @@ int bg_bn_train_fwd(const float* x, float* y, int M, int C, const float* gamma, 
   return L.done("bn_apply_kernel");
 }
 
+int bg_bn_train_fwd_partials(const float* partial_d, int nrows, const float* x, float* y, int M, int C, const float* gamma,
+                             const float* beta, float* moving_mean, float* moving_var, float* save_mean, float* save_inv, float eps,
+                             float momentum, int unbiased, float lrelu_alpha, void* stream) {
+  BG_REQUIRE(partial_d && x && y && gamma && beta && save_mean && save_inv, BG_ERR_NULL, "bg_bn_train_fwd_partials: null pointer");
+  BG_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), BG_ERR_NULL, "bg_bn_train_fwd_partials: moving_mean/var must both be given or both NULL");
+  BG_REQUIRE(M > 0 && C > 0 && nrows > 0, BG_ERR_BAD_SHAPE, "bg_bn_train_fwd_partials: M=%d C=%d nrows=%d", M, C, nrows);
+  const size_t total = (size_t)M * C;
+  {
+    bg::Launch L(stream, "bn_stats_final", 0, 0);
+    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial_d, nrows, M, C, save_mean, save_inv,
+                       moving_mean, moving_var, eps, momentum, unbiased);
+    int rc = L.done("bn_stats_final_kernel");
+    if (rc) return rc;
+  }
+  bg::Launch L(stream, "bn_apply_lrelu", 0, 8.0 * total);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, save_mean, save_inv, 0, eps,
+                     lrelu_alpha);
+  return L.done("bn_apply_kernel");
+}
+
+int bg_bn_sums_from_partials(const float* partial_d, int nrows, int C, float* sums_d, void* stream) {
+  BG_REQUIRE(partial_d && sums_d, BG_ERR_NULL, "bg_bn_sums_from_partials: null pointer");
+  BG_REQUIRE(C > 0 && nrows > 0, BG_ERR_BAD_SHAPE, "bg_bn_sums_from_partials: C=%d nrows=%d", C, nrows);
+  bg::Launch L(stream, "bn_stats_final", 0, 0);
+  hipLaunchKernelGGL(partials_to_sums_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial_d, nrows, C, sums_d);
+  return L.done("partials_to_sums_kernel");
+}
+
 int bg_bn_infer_fwd(const float* x, float* y, int M, int C, const float* gamma, const float* beta, const float* moving_mean,
                     const float* moving_var, float eps, float lrelu_alpha, void* stream) {
   BG_REQUIRE(x && y && gamma && beta && moving_mean && moving_var, BG_ERR_NULL, "bg_bn_infer_fwd: null pointer");

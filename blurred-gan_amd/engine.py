@@ -10,6 +10,7 @@ tanh] [+ Dropout]; Reshape / Flatten are views.  Stage fusion on the device:
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import numpy as np
@@ -88,6 +89,14 @@ class Context:
             lst[i] = torch.empty((self.B,) + self._net.stages[i].out_shape, dtype=torch.float32, device=self._device)
         return lst[i]
 
+    def bn_partials(self, i, rows, C):
+        """Room for the per-workgroup BatchNorm statistics the conv of stage i leaves behind (bg_epilogue.stats)."""
+        key = ("bn_partials", i)
+        n = rows * 2 * C
+        if key not in self._extra or self._extra[key].numel() < n:
+            self._extra[key] = torch.empty(n, dtype=torch.float32, device=self._device)
+        return self._extra[key]
+
     def bn_sums(self, i, C):
         key = ("bn_sums", i)
         if key not in self._extra:
@@ -163,6 +172,7 @@ class Net:
         self._splitk_bytes = {}
         self.rng_offset = 0
         self.sync_bn = True       # data parallel: BatchNormalization statistics over the global batch
+        self.fuse_bn_stats = not os.environ.get("BGAN_NO_FUSED_BN_STATS")   # statistics in the producing conv's epilogue
 
     # ------------------------------------------------------------------ resources
     def context(self, B, tag="default", drop_rows=None) -> Context:
@@ -279,6 +289,7 @@ class Net:
                         ops.keep_mask(keep, 1.0 - st.drop, seed, self.rng_offset)
                         self.rng_offset += (keep.numel() + 3) // 4
                 mi += 1
+            stat_rows = 0          # rows of BatchNorm statistics partials the conv left behind (0: none)
             if st.kind == "dense":
                 K, N = st.in_shape[0], st.out_shape[0]
                 ops.gemm(xin, st.lin.vars["kernel"], tgt, B, N, K, bias=bias)
@@ -299,7 +310,13 @@ class Net:
                     epi = self._epi(*geom, EPI_AFFINE_LRELU, bias=sc[C:], ref=sc[:C], alpha=st.alpha)
                     tgt = out
                 elif st.bn is not None:
-                    epi = self._epi(*geom, EPI_NONE, bias=bias)
+                    # training BatchNorm behind a bias-free conv: the MFMA kernel leaves the column sums of what it stores
+                    # (one row per workgroup); at most one workgroup per 32 output rows and sub-pixel phase
+                    stats = None
+                    if training and bias is None and self.fuse_bn_stats:
+                        C = st.out_shape[-1]
+                        stats = ctx.bn_partials(i, int(np.prod((B,) + st.out_shape[:-1])) // 32 + 64, C)
+                    epi = self._epi(*geom, EPI_NONE, bias=bias, stats=stats)
                 elif st.act == "lrelu":
                     epi = self._epi(*geom, EPI_BIAS_LRELU, bias=bias, keep=keep, alpha=st.alpha,
                                     scale=1.0 / (1.0 - st.drop) if st.drop else 1.0,
@@ -312,19 +329,27 @@ class Net:
                     ops.conv2d_fwd(xin, self.store.transposed_kernel(st.lin), tgt, st.lin.k, st.lin.stride, epi)
                 else:   # Conv2DTranspose forward == data-gradient of the conv with the same kernel array
                     ops.conv2d_bwd_data(xin, st.lin.vars["kernel"], tgt, st.lin.k, st.lin.stride, epi)
+                stat_rows = ops.conv2d_stats_rows() if (st.bn is not None and epi.stats) else 0
             if st.bn is not None and not (st.kind != "dense" and not training and bias is None):
                 C = st.out_shape[-1]
                 M = tgt.numel() // C
                 bn = st.bn
                 if training and self.sync_bn and dist.collectives_active():
                     # SyncBN: batch statistics over the GLOBAL batch -- all-reduce the per-channel sums
-                    ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
                     sums = ctx.bn_sums(i, C)
-                    ops.bn_stats(tgt, M, C, sums, ws)
+                    if stat_rows:
+                        ops.bn_sums_from_partials(ctx.bn_partials(i, stat_rows, C), stat_rows, C, sums)
+                    else:
+                        ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
+                        ops.bn_stats(tgt, M, C, sums, ws)
                     dist.all_reduce_sum_(sums)
                     ops.bn_finalize(sums, M * dist.world_size(), C, ctx.mean[i], ctx.inv[i], bn.vars["moving_mean"],
                                     bn.vars["moving_variance"], eps=bn.epsilon, momentum=bn.momentum, unbiased=(len(st.out_shape) == 3))
                     ops.bn_apply(tgt, out, M, C, bn.vars["gamma"], bn.vars["beta"], ctx.mean[i], ctx.inv[i], lrelu_alpha=st.alpha)
+                elif training and stat_rows:
+                    ops.bn_train_fwd_partials(ctx.bn_partials(i, stat_rows, C), stat_rows, tgt, out, M, C, bn.vars["gamma"], bn.vars["beta"],
+                                              bn.vars["moving_mean"], bn.vars["moving_variance"], ctx.mean[i], ctx.inv[i], eps=bn.epsilon,
+                                              momentum=bn.momentum, unbiased=(len(st.out_shape) == 3), lrelu_alpha=st.alpha)
                 elif training:
                     ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
                     ops.bn_train_fwd(tgt, out, M, C, bn.vars["gamma"], bn.vars["beta"], bn.vars["moving_mean"],

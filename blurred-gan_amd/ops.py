@@ -68,9 +68,11 @@ def conv2d_splitk_workspace_bytes(bwd_data, B, H, W, Cin, Cout, ksize, stride):
     return _lib.load().bg_conv2d_splitk_workspace_bytes(int(bwd_data), B, H, W, Cin, Cout, ksize, stride)
 
 
-def epilogue(mode=EPI_NONE, bias=None, ref=None, keep=None, alpha=LRELU_ALPHA, scale=1.0, ws=None, keep_elems=0):
+def epilogue(mode=EPI_NONE, bias=None, ref=None, keep=None, alpha=LRELU_ALPHA, scale=1.0, ws=None, keep_elems=0, stats=None):
     e = Epilogue()
     e.keep_elems = int(keep_elems)
+    e.stats = stats.data_ptr() if stats is not None else None
+    e.stats_capacity = stats.numel() if stats is not None else 0
     e.splitk_ws = ws.data_ptr() if ws is not None else None
     e.splitk_ws_bytes = ws.numel() * ws.element_size() if ws is not None else 0
     e.mode = mode
@@ -78,7 +80,7 @@ def epilogue(mode=EPI_NONE, bias=None, ref=None, keep=None, alpha=LRELU_ALPHA, s
     e.ref = ref.data_ptr() if ref is not None else None
     e.keep = keep.data_ptr() if keep is not None else None
     e.alpha, e.scale = alpha, scale
-    e._hold = (bias, ref, keep, ws)  # keep the tensors alive for the duration of the launch call
+    e._hold = (bias, ref, keep, ws, stats)  # keep the tensors alive for the duration of the launch call
     return e
 
 
@@ -195,6 +197,26 @@ def bn_train_fwd(x, y, M, Cc, gamma, beta, moving_mean, moving_var, save_mean, s
                                       _ptr(save_mean), _ptr(save_inv), eps, momentum, int(unbiased), lrelu_alpha, _ptr(ws),
                                       ws.numel() * ws.element_size(), _stream()), "bg_bn_train_fwd")
     return y
+
+
+def conv2d_stats_rows():
+    """Rows of epilogue(stats=...) the last conv2d_fwd / conv2d_bwd_data call wrote (0: run the normal statistics pass)."""
+    return _lib.load().bg_conv2d_stats_rows()
+
+
+def bn_train_fwd_partials(partial, nrows, x, y, M, Cc, gamma, beta, moving_mean, moving_var, save_mean, save_inv, eps=1e-3, momentum=0.99,
+                          unbiased=True, lrelu_alpha=LRELU_ALPHA):
+    _f32(x, y, partial)
+    assert x.numel() == M * Cc == y.numel() and partial.numel() >= nrows * 2 * Cc
+    check(_lib.load().bg_bn_train_fwd_partials(_ptr(partial), nrows, _ptr(x), _ptr(y), M, Cc, _ptr(gamma), _ptr(beta), _ptr(moving_mean),
+                                               _ptr(moving_var), _ptr(save_mean), _ptr(save_inv), eps, momentum, int(unbiased), lrelu_alpha,
+                                               _stream()), "bg_bn_train_fwd_partials")
+    return y
+
+
+def bn_sums_from_partials(partial, nrows, Cc, sums):
+    check(_lib.load().bg_bn_sums_from_partials(_ptr(partial), nrows, Cc, _ptr(sums), _stream()), "bg_bn_sums_from_partials")
+    return sums
 
 
 def bn_infer_fwd(x, y, M, Cc, gamma, beta, moving_mean, moving_var, eps=1e-3, lrelu_alpha=LRELU_ALPHA):

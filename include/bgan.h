@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BG_ABI_VERSION 1
+#define BG_ABI_VERSION 2
 
 typedef enum {
   BG_OK = 0,
@@ -101,7 +101,15 @@ typedef struct {
   size_t keep_elems;      /* the keep mask covers output elements [0, keep_elems) only (a batch whose leading samples ran with
                            * Dropout and whose trailing samples without: fake+real and x-hat of wgan.py:138,240 in one pass);
                            * 0 = every element */
+  float* stats;           /* optional (mode BG_EPI_NONE, no bias): the MFMA gather kernel also leaves per-workgroup column sums and
+                           * sums of squares of what it stores -- partial[row][2][Cout] -- so that the BatchNormalization that
+                           * follows (demo_celeba.py:62-90) needs no statistics pass over the tensor; bg_conv2d_stats_rows() tells
+                           * how many rows the last call wrote (0: this geometry took another kernel, run the normal pass) */
+  size_t stats_capacity;  /* floats available behind `stats` */
 } bg_epilogue;
+
+/* rows of epi->stats written by this thread's last bg_conv2d_fwd / bg_conv2d_bwd_data call (0 = none) */
+int bg_conv2d_stats_rows(void);
 
 /* bytes of split-K scratch the forward (bwd_data = 0) / data-gradient (bwd_data = 1) call can use; 0 = never splits */
 size_t bg_conv2d_splitk_workspace_bytes(int bwd_data, int B, int H, int W, int Cin, int Cout, int ksize, int stride);
@@ -160,6 +168,13 @@ int bg_bn_finalize_f32(const float* sums_d, int M_total, int C, float* save_mean
                        float* moving_var, float eps, float momentum, int unbiased, void* stream);
 int bg_bn_apply_f32(const float* x, float* y, int M, int C, const float* gamma, const float* beta, const float* mean,
                     const float* inv, float lrelu_alpha, void* stream);
+/* training-mode BatchNormalization + LeakyReLU from statistics PARTIALS partial[nrows][2][C] (column sums, sums of squares) left
+   by the producing conv (bg_epilogue.stats): finalize (+ moving statistics) and apply, no statistics pass over x */
+int bg_bn_train_fwd_partials(const float* partial_d, int nrows, const float* x, float* y, int M, int C, const float* gamma,
+                             const float* beta, float* moving_mean, float* moving_var, float* save_mean, float* save_inv, float eps,
+                             float momentum, int unbiased, float lrelu_alpha, void* stream);
+/* sums[0:C] = column sums, sums[C:2C] = sums of squares out of the same partials (SyncBN: what gets all-reduced) */
+int bg_bn_sums_from_partials(const float* partial_d, int nrows, int C, float* sums_d, void* stream);
 int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, int C, const float* save_mean,
                         const float* save_inv, float lrelu_alpha, float* sums_d, void* ws_d, size_t ws_bytes, void* stream);
 int bg_bn_bwd_apply_f32(const float* dy, const float* y, const float* x, float* dx, int M, int M_total, int C, const float* gamma,

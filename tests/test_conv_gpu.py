@@ -253,3 +253,44 @@ def test_conv_random_shapes(B, H, W, Ci, Co, s):
     ws = torch.empty(nb // 4 + 4, device="cuda") if nb else None
     dw = ops.conv2d_bwd_filter(dev(x), dev(dy), torch.empty(w.shape, device="cuda"), 5, s, 0.0, 1.0, ws)
     np.testing.assert_allclose(dw.cpu().numpy(), refw, rtol=1e-4, atol=conv_tol(dy[..., 0].size, np.abs(refw).max()))
+
+
+@pytest.mark.parametrize("B,H,W,Ci,Co,s,bwd", [
+    (8, 32, 32, 64, 128, 2, True), (8, 64, 64, 32, 64, 2, True),       # ConvT 128->64 and 64->32 as data gradients: 64x64 and 128x32 tiles, 4 phases
+    (130, 8, 8, 128, 256, 2, True),                                       # position-major tiles, padding taps skipped, ragged last M tile
+    (1024, 16, 16, 16, 32, 2, True),                                      # four phases merged in one workgroup
+    (3, 16, 16, 64, 128, 1, False), (5, 9, 7, 32, 64, 2, False),          # forward, stride 1 / odd sizes (phases of different extents)
+])
+def test_conv_epilogue_leaves_batchnorm_statistics(B, H, W, Ci, Co, s, bwd):
+    """bg_epilogue.stats: the gather-GEMM also writes one row of column sums / sums of squares per workgroup; summed over the rows
+    they equal the statistics of the tensor it stored (what the BatchNormalization behind a Conv2DTranspose needs,
+    demo_celeba.py:62-90).  A geometry that takes another kernel family reports 0 rows."""
+    from blurred_gan_amd import ops
+    x, w, dy = _data(B, H, W, Ci, Co, s, seed=3)
+    if bwd:
+        src, wd = dev(dy), dev(w).reshape(25, Ci, Co)
+        out = torch.empty(B, H, W, Ci, device="cuda")
+        N = Ci
+    else:
+        wT = ops.transpose_last2(dev(w), torch.empty(w.size, device="cuda"), 25, Ci, Co)
+        src = dev(x)
+        out = torch.empty(B, -(-H // s), -(-W // s), Co, device="cuda")
+        N = Co
+    stats = torch.full(((out.numel() // N // 32 + 64) * 2 * N,), float("nan"), device="cuda")
+    epi = ops.epilogue(stats=stats)
+    if bwd:
+        ops.conv2d_bwd_data(src, wd, out, 5, s, epi)
+    else:
+        ops.conv2d_fwd(src, wT, out, 5, s, epi)
+    rows = ops.conv2d_stats_rows()
+    assert rows > 0, "this geometry is expected on the MFMA gather kernel without split-K"
+    part = stats[:rows * 2 * N].view(rows, 2, N).double().cpu().numpy()
+    assert np.isfinite(part).all(), "every partial row must have been written"
+    flat = out.view(-1, N).double().cpu().numpy()
+    scale = np.abs(flat).max()
+    np.testing.assert_allclose(part[:, 0].sum(0), flat.sum(0), rtol=1e-5, atol=2e-5 * scale * np.sqrt(flat.shape[0]))
+    np.testing.assert_allclose(part[:, 1].sum(0), (flat ** 2).sum(0), rtol=1e-5, atol=1e-6)
+    # a thin layer goes to another kernel family: no rows, the caller runs the normal statistics pass
+    o2 = torch.empty(2, 16, 16, 3, device="cuda")
+    ops.conv2d_fwd(torch.rand(2, 16, 16, 32, device="cuda"), torch.rand(25 * 3 * 32, device="cuda"), o2, 5, 1, ops.epilogue(stats=stats))
+    assert ops.conv2d_stats_rows() == 0
