@@ -496,12 +496,18 @@ __global__ __launch_bounds__(256, BLUR_COLS_WPS) void blur_cols_kernel(const flo
 #pragma unroll
   for (int p = 0; p < 3; ++p) Ya[p] = Yb[p] = Yc[p] = floatx4{0.f, 0.f, 0.f, 0.f};
   int b = bl - 1;
-  gload(b);
-  xstore();
+  const int nblk_img = (H + 15) >> 4;
+  // a block wholly outside the image (above the first segment, below the last) is zeros: no loads, no W pass
+  auto inside = [&](int blk) { return blk >= 0 && blk < nblk_img; };
+  if (inside(b)) { gload(b); xstore(); }
   // one block step; Y2 receives block b, Y0 / Y1 hold blocks b-2 / b-1
   auto step = [&](floatx4 (&Y0)[3], floatx4 (&Y1)[3], floatx4 (&Y2)[3]) {
-    gload(b + 1);                                              // in flight under this step's MFMAs (past the segment: wasted, harmless)
-    {
+    const bool next_in = b + 1 <= bh && inside(b + 1);         // wave-uniform
+    if (next_in) gload(b + 1);                                 // in flight under this step's MFMAs
+    if (!inside(b)) {
+#pragma unroll
+      for (int p = 0; p < 3; ++p) Y2[p] = floatx4{0.f, 0.f, 0.f, 0.f};
+    } else {
       // operand reads in groups of 4 k-steps, one group ahead of the MFMAs that consume them (all at once costs 12 more live
       // registers and a wave per SIMD)
       constexpr int GS = 4, NG = (NK + GS - 1) / GS;
@@ -591,7 +597,7 @@ __global__ __launch_bounds__(256, BLUR_COLS_WPS) void blur_cols_kernel(const flo
         }
       }
     }
-    xstore();                                                  // block b+1 replaces block b (every read of b has been issued)
+    if (next_in) xstore();                                     // block b+1 replaces block b (every read of b has been issued)
     ++b;
   };
   // the two older blocks move down by register copies (24 v_mov per 72 MFMAs): one step body instead of three rotated ones
