@@ -184,3 +184,22 @@ def test_demo_under_two_ranks_one_run_directory_and_lockstep_replicas(tmp_path):
     assert hp["global_batch_size"] == 8 and hp["batch_size"] == 4
     for tag in ("d", "g"):
         np.testing.assert_array_equal(np.load(tmp_path / f"demo_{tag}_theta_0.npy"), np.load(tmp_path / f"demo_{tag}_theta_1.npy"))
+
+
+def test_local_rank_beyond_visible_devices_is_an_error(monkeypatch):
+    """More local ranks than GPUs must fail loudly (two RCCL ranks on one card hang inside the first collective); sharing a card
+    is an explicit rehearsal switch."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from blurred_gan_amd import dist
+    n = torch.cuda.device_count()
+    monkeypatch.setenv("LOCAL_RANK", str(n))
+    monkeypatch.delenv("BGAN_DIST_SHARE_DEVICES", raising=False)
+    monkeypatch.delenv("BGAN_DIST_BACKEND", raising=False)
+    with pytest.raises(RuntimeError, match="LOCAL_RANK"):
+        dist.local_rank()
+    monkeypatch.setenv("BGAN_DIST_SHARE_DEVICES", "1")
+    assert dist.local_rank() == 0
+    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.delenv("BGAN_DIST_SHARE_DEVICES", raising=False)
+    assert dist.local_rank() == 0
