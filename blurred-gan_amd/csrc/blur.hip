@@ -390,7 +390,7 @@ struct StripCfg {
   static constexpr int NLD = 32 * F4 / 256;                   // float4 per thread per chunk
   static constexpr int TZ = 128;                              // zero-padded taps table: index k - n - P + taps/2 + 48 in [0, 128)
   static constexpr size_t lds_bytes = ((size_t)32 * XS + (size_t)RB * 16 * YS + TZ) * sizeof(float);
-  static_assert(P % 4 == 0 && P >= 4 && P <= 32, "band reach");
+  static_assert(P % 4 == 0 && P >= 4 && P <= 32, "band reach");     // instantiated for 24 and 32 (35..65 taps)
   static_assert(32 * F4 % 256 == 0, "chunk loads must divide evenly");
 };
 
@@ -960,9 +960,7 @@ int launch_strip(dim3 grid, hipStream_t s, const float* x, float* y, int B, int 
 
 template <int C>
 int launch_strip_c(int reach, dim3 grid, hipStream_t s, const float* x, float* y, int B, int H, int W, int strips, const float* taps, int T, void* dbg) {
-  if (reach <= 4) return launch_strip<C, 4>(grid, s, x, y, B, H, W, strips, taps, T, dbg);
-  if (reach <= 8) return launch_strip<C, 8>(grid, s, x, y, B, H, W, strips, taps, T, dbg);
-  if (reach <= 16) return launch_strip<C, 16>(grid, s, x, y, B, H, W, strips, taps, T, dbg);
+  // band reach <= 16 (up to 33 taps) belongs to blur_cols_kernel; the workgroup form serves 35..65 taps
   if (reach <= 24) return launch_strip<C, 24>(grid, s, x, y, B, H, W, strips, taps, T, dbg);
   return launch_strip<C, 32>(grid, s, x, y, B, H, W, strips, taps, T, dbg);
 }
@@ -1017,7 +1015,9 @@ int bg_gauss_kernel_1d(float sigma_eff, float kernel_size, float* taps_host, int
 static int blur_path(int B, int H, int W, int C, int n_taps) {
   static const int strip_min = getenv("BG_BLUR_STRIP_MIN_SIZE") ? atoi(getenv("BG_BLUR_STRIP_MIN_SIZE")) : 65;
   static const int strip_max_taps = getenv("BG_BLUR_STRIP_MAX_TAPS") ? atoi(getenv("BG_BLUR_STRIP_MAX_TAPS")) : 65;
-  if ((C == 1 || C == 3) && ((W * C) & 3) == 0 && n_taps <= std::min(strip_max_taps, 65) && (H >= strip_min || W >= strip_min)) return 4;
+  if ((C == 1 || C == 3) && ((W * C) & 3) == 0 && n_taps <= std::min(strip_max_taps, 65) && (H >= strip_min || W >= strip_min) &&
+      (size_t)H * W * C < (1u << 29))        // per-image buffer descriptors: 32-bit byte offsets
+    return 4;
   static const int mfma_min_taps = getenv("BG_BLUR_MFMA_MIN_TAPS") ? atoi(getenv("BG_BLUR_MFMA_MIN_TAPS")) : 13;
   static const int band_t_min = getenv("BG_BLUR_BANDT_MIN_TAPS") ? atoi(getenv("BG_BLUR_BANDT_MIN_TAPS")) : 13;
   const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
@@ -1076,8 +1076,7 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   if (path == 4) {
     const int strips = (int)bg::cdiv(W, kSP);
     const dim3 grid((unsigned)(8 * bg::cdiv(B, 8) * strips));
-    static const int no_cols = getenv("BG_BLUR_NO_COLS") ? 1 : 0;
-    if ((n_taps >> 1) <= 16 && !no_cols && (size_t)H * W * C < (1u << 29)) {
+    if ((n_taps >> 1) <= 16) {
       bg::Launch L(stream, "blur_cols", flops, bytes);
       const int rc = C == 3 ? launch_cols_c<3>(n_taps >> 1, s, x, y, B, H, W, taps_d, n_taps, tmp_d) : launch_cols_c<1>(n_taps >> 1, s, x, y, B, H, W, taps_d, n_taps, tmp_d);
       if (rc) return rc;
