@@ -182,175 +182,330 @@ __global__ __launch_bounds__(kMfmaBlurThreads) void blur_mfma_kernel(const float
 // (traffic 2x algorithmic), restricted to the BAND: an output block of 32 rows only contracts over the source rows
 // within half a kernel of it.
 // ------------------------------------------------------------------------------------------------
+// cache policy of the band passes' float4 stores: 2 = nt (streamed; 97 against 100 us at 143 taps with the default policy)
+#ifndef BAND_ST_AUX
+#define BAND_ST_AUX 2
+#endif
 // One pass of the separable blur as  out^T = (T * in)^T : contraction along the LEADING dimension of in[R][S][C] (rows of
 // Q = S*C floats, lanes along Q -> coalesced), result stored TRANSPOSED as out[S][R][C].  Run twice it blurs both directions
 // and lands back in NHWC: x[H][W][C] -> tmp[W][H][C] -> y[H][W][C]; the W direction never needs the C-times-sparser
 // Toeplitz matrix an interleaved row would ask for.
-// Workgroup = 128 output rows (one 32-row block per wave) x 4 column tiles; a column tile is the 32/C whole pixels that fit 32
-// MFMA columns, so the transposed store of one pixel column is 32*C contiguous floats.  Source rows stream through LDS in chunks
-// of 32 (float4 loads, double-buffered, shared by the four waves: every source element is fetched once per workgroup); a wave
-// skips the chunks outside its own band.
-constexpr int kBtRows = 128, kBtChunk = 32, kBtPad = 64;
+//
+// Workgroup = 128 output rows x NW column tiles of 32 floats; a WAVE owns one column tile for all four 32-row blocks, so the
+// source columns it contracts over are its own: every wave streams its 32 columns down the band through a PRIVATE
+// double-buffered LDS chunk (32 rows x 32 floats) and transposes its own results -- after the taps table is up there is no
+// barrier in the kernel (with a barrier per chunk and a chunk shared by the workgroup the matrix pipe was 65 % busy inside the
+// loop, 82 % without: s_memtime stamps, tools/band_placement.py).
+// Source rows are addressed relative to k0 = r0 - half in STAGES of 8 rows (4 MFMA k-pairs): row block jb contracts over the
+// stages of rows [32 jb, 32 jb + 32 + T - 1), the same for every workgroup, and its Toeplitz fragment of stage s is
+// tz[PadLo + 8 s + 2 u + kk - 32 jb - li] from a zero-padded table (partial last stage: zero taps; rows outside the image:
+// zeros in the chunk, whole stages outside it skipped).  The operand reads of stage s + 1 (4 source + 16 Toeplitz values,
+// ds_read2) are issued before the MFMAs of stage s into the other of two register sets; the next chunk's global loads fly
+// for three stages before they are written to LDS.
+// A row block leaves one chunk after its band is through (blocks 0..2 beside the MFMAs of the blocks below, only the last one
+// in the tail): the wave lays its 32 x 32 tile out as [pixel column][row][channel] in the chunk buffer it is about to leave
+// and stores whole pixel columns (32*C contiguous floats of the transposed image) as float4, a quarter per stage; with 3
+// channels a 32-float tile starts and ends inside a pixel, and those two partial columns go out as single floats.
+constexpr int kBtRows = 128, kBtPadLo = 128, kBtPadHi = 208;
+constexpr int kBtWS = 40;             // chunk row stride: 32 x 40 floats also hold the transposed tile of a row block
 
-// Geometry: a wave owns ONE MFMA column tile of 32 floats for all four 32-row blocks of the workgroup (equal band structure in
-// every wave: nobody idles at the chunk barriers).  The workgroup's column span is a whole number of pixels: 4 tiles = 128 / C
-// pixels for 1, 2 and 4 channels; for 3 channels THREE tiles = 96 floats = 32 pixels (192-thread workgroups) -- no MFMA column
-// is padding (10-pixel tiles would idle 2 of 32), a 256-pixel line is 8 groups with no ragged last group, and 64 x 256x256x3
-// is 1024 workgroups = 4 per CU on every CU (7 groups of 40 pixels were 896: 3.5 per CU, the launch as long as the CUs with 4).
+// Geometry: the workgroup's column span is a whole number of pixels: 4 tiles = 128 / C pixels for 1, 2 and 4 channels; for 3
+// channels THREE tiles = 96 floats = 32 pixels (192-thread workgroups) -- a 256-pixel line is 8 groups with no ragged last
+// group, and 64 x 256x256x3 is 1024 workgroups = 4 per CU on every CU, 3 waves on every SIMD (placement read back from HW_ID
+// in the -DBLUR_BAND_STAMP build: tools/band_placement.py).
 template <int C>
 struct BandCfg {
   static constexpr int NW = C == 3 ? 3 : 4;                   // waves = MFMA column tiles per workgroup
   static constexpr int NTH = NW * 64;
   static constexpr int COLS = NW * 32;                        // floats per workgroup row
   static constexpr int PXW = COLS / C;                        // whole pixels per workgroup
-  static constexpr int STRIDE = COLS + 4;                     // LDS row stride of a source chunk
   static constexpr int RUN = 32 * C + 4;                      // one pixel column of a transposed 32-row block (+ pad)
-  static constexpr int CHUNK = 2 * kBtChunk * STRIDE;         // double-buffered source chunks (floats)
-  static constexpr int TT = PXW * RUN;                        // transposed block of the whole workgroup
-  static constexpr int BUF = CHUNK > TT ? CHUNK : TT;
+  static constexpr int SLOTS = (32 + 2 * (C - 1)) / C;        // pixel columns a 32-float tile can touch
+  static constexpr int BUF = NW * 2 * 32 * kBtWS;             // per-wave double-buffered source chunks (floats)
   static_assert(COLS % C == 0, "workgroup span must be whole pixels");
+  static_assert(SLOTS * RUN <= 32 * kBtWS, "the transposed tile must fit a chunk buffer");
 };
+inline int band_tz_floats(int T) { return (T + kBtPadLo + kBtPadHi + 3) & ~3; }
 
-template <int C>        // channel count as a compile-time constant: every index division below is by a constant
-__global__ __launch_bounds__(BandCfg<C>::NTH) void blur_band_t_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int S,
+#ifdef BLUR_BAND_STAMP          // diagnostic build only: where and when every wave of the last band pass ran
+__device__ unsigned long long g_band_dbg[4096 * 4];
+#endif
+
+// The four 32 x 32 accumulators of a wave live in a[0:63] BY HAND: the MFMAs, the zeroing and the read-out are asm statements
+// naming the registers (the compiler only learns that they are clobbered).  Through the builtin -- or through asm with
+// allocated operands -- the compiler gives the arms of the band's control flow their own copies of the accumulators (128 AGPRs
+// plus moves; capped at three waves per SIMD it spills them), and the band needs that control flow: stages that all four row
+// blocks cover issue k-pair major, consecutive MFMAs going to different accumulators, the others block by block.  (A build
+// with every memory instruction knocked out runs the MFMAs of a pass in 36 us that way against 50 with dependent chains of
+// four throughout; in the full kernel the difference is 4 % at 255 taps and nothing at 143.)
+// The compiler does not see MFMAs here: the wait states between the last MFMA and the VALU read of its result are in band_acc_read.
+#define BAND_CL0 "a0", "a1", "a2", "a3", "a4", "a5", "a6", "a7", "a8", "a9", "a10", "a11", "a12", "a13", "a14", "a15"
+#define BAND_CL1 "a16", "a17", "a18", "a19", "a20", "a21", "a22", "a23", "a24", "a25", "a26", "a27", "a28", "a29", "a30", "a31"
+#define BAND_CL2 "a32", "a33", "a34", "a35", "a36", "a37", "a38", "a39", "a40", "a41", "a42", "a43", "a44", "a45", "a46", "a47"
+#define BAND_CL3 "a48", "a49", "a50", "a51", "a52", "a53", "a54", "a55", "a56", "a57", "a58", "a59", "a60", "a61", "a62", "a63"
+template <int JB>
+__device__ __forceinline__ void band_mfma(float a, float b) {
+  if constexpr (JB == 0) asm volatile("v_mfma_f32_32x32x2_f32 a[0:15], %0, %1, a[0:15]" ::"v"(a), "v"(b) : BAND_CL0);
+  if constexpr (JB == 1) asm volatile("v_mfma_f32_32x32x2_f32 a[16:31], %0, %1, a[16:31]" ::"v"(a), "v"(b) : BAND_CL1);
+  if constexpr (JB == 2) asm volatile("v_mfma_f32_32x32x2_f32 a[32:47], %0, %1, a[32:47]" ::"v"(a), "v"(b) : BAND_CL2);
+  if constexpr (JB == 3) asm volatile("v_mfma_f32_32x32x2_f32 a[48:63], %0, %1, a[48:63]" ::"v"(a), "v"(b) : BAND_CL3);
+}
+__device__ __forceinline__ void band_acc_zero() {
+  asm volatile(".irp r,0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,35,36,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63\n\tv_accvgpr_write_b32 a\\r, 0\n\t.endr\n\ts_nop 3" ::
+               : BAND_CL0, BAND_CL1, BAND_CL2, BAND_CL3);
+}
+#define BAND_RD16_OUT "=v"(v[0]), "=v"(v[1]), "=v"(v[2]), "=v"(v[3]), "=v"(v[4]), "=v"(v[5]), "=v"(v[6]), "=v"(v[7]), "=v"(v[8]), "=v"(v[9]), \
+                      "=v"(v[10]), "=v"(v[11]), "=v"(v[12]), "=v"(v[13]), "=v"(v[14]), "=v"(v[15])
+#define BAND_SETTLE "s_nop 15\n\ts_nop 7\n\t"          /* 16-pass MFMA -> VALU read of its result: 18 wait states */
+__device__ __forceinline__ void band_acc_read(int jb, float (&v)[16]) {      // jb uniform
+  switch (jb) {
+    case 0: asm volatile(BAND_SETTLE "v_accvgpr_read_b32 %0, a0\n\t" "v_accvgpr_read_b32 %1, a1\n\t" "v_accvgpr_read_b32 %2, a2\n\t" "v_accvgpr_read_b32 %3, a3\n\t" "v_accvgpr_read_b32 %4, a4\n\t" "v_accvgpr_read_b32 %5, a5\n\t" "v_accvgpr_read_b32 %6, a6\n\t" "v_accvgpr_read_b32 %7, a7\n\t" "v_accvgpr_read_b32 %8, a8\n\t" "v_accvgpr_read_b32 %9, a9\n\t" "v_accvgpr_read_b32 %10, a10\n\t" "v_accvgpr_read_b32 %11, a11\n\t" "v_accvgpr_read_b32 %12, a12\n\t" "v_accvgpr_read_b32 %13, a13\n\t" "v_accvgpr_read_b32 %14, a14\n\t" "v_accvgpr_read_b32 %15, a15\n\t" : BAND_RD16_OUT); break;
+    case 1: asm volatile(BAND_SETTLE "v_accvgpr_read_b32 %0, a16\n\t" "v_accvgpr_read_b32 %1, a17\n\t" "v_accvgpr_read_b32 %2, a18\n\t" "v_accvgpr_read_b32 %3, a19\n\t" "v_accvgpr_read_b32 %4, a20\n\t" "v_accvgpr_read_b32 %5, a21\n\t" "v_accvgpr_read_b32 %6, a22\n\t" "v_accvgpr_read_b32 %7, a23\n\t" "v_accvgpr_read_b32 %8, a24\n\t" "v_accvgpr_read_b32 %9, a25\n\t" "v_accvgpr_read_b32 %10, a26\n\t" "v_accvgpr_read_b32 %11, a27\n\t" "v_accvgpr_read_b32 %12, a28\n\t" "v_accvgpr_read_b32 %13, a29\n\t" "v_accvgpr_read_b32 %14, a30\n\t" "v_accvgpr_read_b32 %15, a31\n\t" : BAND_RD16_OUT); break;
+    case 2: asm volatile(BAND_SETTLE "v_accvgpr_read_b32 %0, a32\n\t" "v_accvgpr_read_b32 %1, a33\n\t" "v_accvgpr_read_b32 %2, a34\n\t" "v_accvgpr_read_b32 %3, a35\n\t" "v_accvgpr_read_b32 %4, a36\n\t" "v_accvgpr_read_b32 %5, a37\n\t" "v_accvgpr_read_b32 %6, a38\n\t" "v_accvgpr_read_b32 %7, a39\n\t" "v_accvgpr_read_b32 %8, a40\n\t" "v_accvgpr_read_b32 %9, a41\n\t" "v_accvgpr_read_b32 %10, a42\n\t" "v_accvgpr_read_b32 %11, a43\n\t" "v_accvgpr_read_b32 %12, a44\n\t" "v_accvgpr_read_b32 %13, a45\n\t" "v_accvgpr_read_b32 %14, a46\n\t" "v_accvgpr_read_b32 %15, a47\n\t" : BAND_RD16_OUT); break;
+    default: asm volatile(BAND_SETTLE "v_accvgpr_read_b32 %0, a48\n\t" "v_accvgpr_read_b32 %1, a49\n\t" "v_accvgpr_read_b32 %2, a50\n\t" "v_accvgpr_read_b32 %3, a51\n\t" "v_accvgpr_read_b32 %4, a52\n\t" "v_accvgpr_read_b32 %5, a53\n\t" "v_accvgpr_read_b32 %6, a54\n\t" "v_accvgpr_read_b32 %7, a55\n\t" "v_accvgpr_read_b32 %8, a56\n\t" "v_accvgpr_read_b32 %9, a57\n\t" "v_accvgpr_read_b32 %10, a58\n\t" "v_accvgpr_read_b32 %11, a59\n\t" "v_accvgpr_read_b32 %12, a60\n\t" "v_accvgpr_read_b32 %13, a61\n\t" "v_accvgpr_read_b32 %14, a62\n\t" "v_accvgpr_read_b32 %15, a63\n\t" : BAND_RD16_OUT); break;
+  }
+}
+
+struct BandFrag { float a[4][4]; float b[4]; };               // operands of one stage: Toeplitz [row block][k-pair], source [k-pair]
+
+// C: channel count as a compile-time constant (index divisions).  LD: how a chunk is loaded -- 2: float4 buffer loads (rows are
+// float4-addressable), 1: dword buffer loads, 0: synchronous 64-bit addressing (images beyond the 32-bit byte offsets of a
+// buffer descriptor)
+template <int C, int LD>
+__global__ __launch_bounds__(BandCfg<C>::NTH, 3) void blur_band_t_kernel(const float* __restrict__ x, float* __restrict__ y, int R, int S,
                                                                         int row_groups, int col_groups, const float* __restrict__ taps, int T) {
   using G = BandCfg<C>;
-  constexpr int NW = G::NW, NTH = G::NTH, COLS = G::COLS, PXW = G::PXW, STRIDE = G::STRIDE, RUN = G::RUN;
+  constexpr int NTH = G::NTH, PXW = G::PXW, RUN = G::RUN, WS = kBtWS;
+  constexpr bool V4 = LD == 2;
   extern __shared__ __attribute__((aligned(16))) float tl[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = T >> 1, Q = S * C;
-  float* tz = tl;                                              // [64 zeros][T][64 zeros]
-  float* Bs = tl + ((T + 2 * kBtPad + 3) & ~3);                // [2][32][STRIDE] source chunks; later the transposed block
-  for (int j = tid; j < T + 2 * kBtPad; j += NTH) tz[j] = (j >= kBtPad && j < kBtPad + T) ? taps[j - kBtPad] : 0.f;
+#ifdef BLUR_BAND_STAMP
+  const unsigned long long st0 = __builtin_amdgcn_s_memtime();
+  unsigned long long st1 = st0;
+#endif
+  const int tzn = (T + kBtPadLo + kBtPadHi + 3) & ~3;
+  float* tz = tl;                                              // [PadLo zeros][T][PadHi zeros]
+  float* wb = tl + tzn + wave * 2 * 32 * WS;                   // this wave's two chunk buffers
   const int per_img = row_groups * col_groups;
-  const int b = blockIdx.x / per_img, u = blockIdx.x - b * per_img;
-  const int rg = u / col_groups, cg = u - rg * col_groups;
+  const int b = blockIdx.x / per_img, u_ = blockIdx.x - b * per_img;
+  const int rg = u_ / col_groups, cg = u_ - rg * col_groups;
   const int r0 = rg * kBtRows, s0 = cg * PXW;
-  const int q0 = s0 * C, ncols = min(COLS, Q - q0);            // this workgroup's source / output columns
+  const int qw = s0 * C + wave * 32;                           // this wave's first source column
+  const int wcols = min(32, Q - qw);                           // <= 0: nothing to contract (ragged last group)
   const int li = lane & 31, kk = lane >> 5;
   const float* xi = x + (size_t)b * R * Q;
   float* yi = y + (size_t)b * R * Q;
-  floatx16 acc[4];
-#pragma unroll
-  for (int j = 0; j < 4; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.f;
-  const int k_lo = max(0, r0 - half) / kBtChunk * kBtChunk, k_hi = min(R, r0 + kBtRows + half);
-  const bool vec4 = (Q & 3) == 0 && (ncols & 3) == 0;
-  // chunk loader: 32 rows x ncols floats, row-contiguous in global memory; NW*8 float4 slots per row, 4 per thread
+  const int k0 = r0 - half, L = 32 + T - 1;
+  const int k_end = min(R, r0 + kBtRows + half);               // source rows needed: [max(0, k0), k_end)
+  const int ci_lo = k0 < 0 ? (-k0) >> 5 : 0, ci_hi = (k_end - k0 + 31) >> 5;         // chunks of 32 rows from k0
+  const int lr = lane >> 3, c4 = lane & 7;                     // loader: 8 float4 per row, rows lr + 8 i
   float4 g[4];
-  auto gload = [&](int kc) {
-    if (vec4) {
-      const int nq4 = ncols >> 2;
+  float gs[LD == 1 ? 16 : 1];                                  // LD == 1: element e = lane + 64 i of the chunk, row e / 32, column e % 32
+  constexpr int kOob = (int)0x80000000;
+  const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xi), 0, LD ? R * Q * 4 : 0, 0x00020000);
+  auto gload = [&](int ci) {
+    if (LD == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int k = k0 + 32 * ci + (lane >> 5) + 2 * i, c = lane & 31;
+        gs[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, (c < wcols && (unsigned)k < (unsigned)R) ? (k * Q + qw + c) * 4 : kOob, 0, 0));
+      }
+    }
+    if (V4) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        const int e = tid + i * NTH, rr = e / (NW * 8), c4 = e - rr * (NW * 8);
-        const int k = kc + rr;
-        g[i] = (c4 < nq4 && k < R) ? *reinterpret_cast<const float4*>(xi + (size_t)k * Q + q0 + 4 * c4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        const int k = k0 + 32 * ci + lr + 8 * i;                  // outside the image: an offset past the descriptor loads zeros
+        g[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(
+                                              rsx, (4 * c4 < wcols && (unsigned)k < (unsigned)R) ? (k * Q + qw + 4 * c4) * 4 : kOob, 0, 0));
       }
     }
   };
-  auto lstore = [&](int buf, int kc) {
-    float* d = Bs + buf * kBtChunk * STRIDE;
-    if (vec4) {
+  auto lstore = [&](int ci) {
+    float* d = wb + (ci & 1) * 32 * WS;
+    if (V4) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int e = tid + i * NTH, rr = e / (NW * 8), c4 = e - rr * (NW * 8);
-        *reinterpret_cast<float4*>(d + rr * STRIDE + 4 * c4) = g[i];
-      }
+      for (int i = 0; i < 4; ++i) *reinterpret_cast<float4*>(d + (lr + 8 * i) * WS + 4 * c4) = g[i];
+    } else if (LD == 1) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) d[((lane >> 5) + 2 * i) * WS + (lane & 31)] = gs[i];
     } else {
-      for (int e = tid; e < kBtChunk * COLS; e += NTH) {
-        const int rr = e / COLS, c = e - rr * COLS;
-        const int k = kc + rr;
-        d[rr * STRIDE + c] = (c < ncols && k < R) ? xi[(size_t)k * Q + q0 + c] : 0.f;
+      for (int e = lane; e < 32 * 32; e += 64) {
+        const int rr = e >> 5, c = e & 31, k = k0 + 32 * ci + rr;
+        d[rr * WS + c] = (c < wcols && (unsigned)k < (unsigned)R) ? xi[(size_t)k * Q + qw + c] : 0.f;
       }
     }
   };
-  gload(k_lo);
-  lstore(0, k_lo);
-  __syncthreads();
-  const float* ta0 = tz + kBtPad + half - (r0 + li) + kk;     // + k - 32*jb
-  int buf = 0;
-  for (int kc = k_lo; kc < k_hi; kc += kBtChunk, buf ^= 1) {
-    const bool more = kc + kBtChunk < k_hi;
-    if (more) gload(kc + kBtChunk);                            // next chunk's loads fly under this chunk's MFMAs
-    {
-      const float* bb = Bs + buf * kBtChunk * STRIDE + kk * STRIDE + wave * 32 + li;
+  if (wcols > 0) gload(ci_lo);                                 // the first chunk flies while the taps table is built
+  for (int j = tid; j < tzn; j += NTH) tz[j] = (j >= kBtPadLo && j < kBtPadLo + T) ? taps[j - kBtPadLo] : 0.f;
+  band_acc_zero();
+  __syncthreads();                                             // the taps table: the only barrier of the kernel
+  if (wcols <= 0) return;
+
+  // transposed store of row block jb from the chunk buffer `tt` (free at the time): tile element (r, q) of pixel column
+  // p = (off + q) / C, channel c goes to tt[p][r*C + c]; whole pixel columns leave as float4 out[((sp)*R + rw0 + r)*C + c]
+  const int off = qw % C, px0 = qw / C;                        // first (maybe partial) pixel column of the tile
+  const bool st4 = LD != 0 && ((R * C) & 3) == 0 && ((uintptr_t)y & 15) == 0;    // float4 runs of the transposed image
+  const __amdgpu_buffer_rsrc_t rsy = __builtin_amdgcn_make_buffer_rsrc(yi, 0, LD ? R * Q * 4 : 0, 0x00020000);
+  auto tile_write = [&](int jb, float* tt) {
+    float a[16];
+    band_acc_read(jb, a);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));                               // indices are recomputed here, not kept in registers across the band
+    const int colp = (ln & 31) + off, px_l = colp / C, c_l = colp - px_l * C, k4 = (ln >> 5) * 4;
+    float* td = tt + px_l * RUN + k4 * C + c_l;
 #pragma unroll
-      for (int jb = 0; jb < 4; ++jb) {
-        // the k-pairs of this chunk inside the band of row block jb (rows r0 + 32*jb - half .. r0 + 32*jb + 31 + half)
-        const int lo = r0 + 32 * jb - half, hi = r0 + 32 * jb + 32 + half;
-        const int kp_lo = max(0, (lo - kc) >> 1), kp_hi = min(kBtChunk / 2, (hi - kc + 1) >> 1);
-        if (r0 + 32 * jb >= R) continue;
-        const float* ta = ta0 - 32 * jb + kc;
-        // groups of 4 k-pairs, software-pipelined: the 8 operand reads of group g+1 are issued before the 4 MFMAs of group g
-        // (256 cycles of matrix work), so the pipe never waits on an LDS round trip inside a band
-        int kp = kp_lo;
-        const int n4 = (kp_hi - kp_lo) >> 2;
-        if (n4 > 0) {
-          float av[4], bv[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) { av[u] = ta[2 * (kp + u)]; bv[u] = bb[2 * (kp + u) * STRIDE]; }
-          for (int gq = 0; gq < n4; ++gq) {
-            float an[4], bn[4];
-            const int kn = gq + 1 < n4 ? kp + 4 : kp;         // last group: re-read itself (harmless) instead of branching
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { an[u] = ta[2 * (kn + u)]; bn[u] = bb[2 * (kn + u) * STRIDE]; }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u], bv[u], acc[jb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) { av[u] = an[u]; bv[u] = bn[u]; }
-            kp += 4;
+    for (int q = 0; q < 16; ++q) td[((q & 3) + 8 * (q >> 2)) * C] = a[q];
+  };
+  // One quarter (part 0..3) of the read-out of row block jb's tile: a row block drains over the four stages after its tile
+  // was written, so that the waves of the launch, which run in step, do not all write a whole block at the same moment.
+  // (Knock-out builds price the stores at 19 of 101 us at 143 taps, 10 of them the float4 store instructions themselves;
+  // spreading them changed nothing measurable, the streaming cache policy 3 us.)
+  auto drain = [&](int jb, const float* tt, int part) {
+    const int rw0 = r0 + 32 * jb;
+    const int nrow = min(32, R - rw0);
+    int ln = lane;
+    asm volatile("" : "+v"(ln));
+    __builtin_amdgcn_wave_barrier();
+    const int p_full_lo = off ? 1 : 0, p_full_hi = (off + wcols) / C;        // slots [lo, hi) hold all C channels
+    if (st4 && nrow == 32) {
+      const int obase = (px0 * R + rw0) * C;                   // float offset of (first slot, first row) in the transposed image
+      const int f = ln + 64 * part;                            // at most 32 * 8 float4 in the full columns: four rounds
+      if (f < (p_full_hi - p_full_lo) * 8 * C) {
+        const int p = p_full_lo + f / (8 * C), w4 = f % (8 * C);
+        typedef unsigned u4 __attribute__((ext_vector_type(4)));
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, *reinterpret_cast<const float4*>(tt + p * RUN + 4 * w4)), rsy,
+                                               (obase + p * R * C + 4 * w4) * 4, 0, BAND_ST_AUX);
+      }
+      // the partial columns at either end of the tile: single floats.  Only 3 channels have them (32 % C == 0 otherwise),
+      // holding 1 or 2 of the 3 channels: n - 1 is the mask / shift of the (row, channel) split
+      if constexpr (C == 3) {
+        if (part == 0 && off) {
+          const int n = C - off, e = ln;
+          if (e < 32 * n) {
+            const int r = e >> (n - 1), c = off + (e & (n - 1));
+            yi[(size_t)obase + r * C + c] = tt[r * C + c];
           }
         }
-        for (; kp < kp_hi; ++kp)
-          acc[jb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[2 * kp], bb[2 * kp * STRIDE], acc[jb], 0, 0, 0);
-      }
-    }
-    if (more) lstore(buf ^ 1, kc + kBtChunk);
-    __syncthreads();
-  }
-  // transposed store, one 32-row block of the whole workgroup at a time: tile element (r, q) with q = px*C + c goes to
-  // TT[px][r*C + c] in LDS (the chunk buffers are free after the last barrier), so that the 32*C floats of one pixel column
-  // leave contiguously as float4:  out[(px*R + r)*C + c]
-  float* tt = Bs;
-  const int col = wave * 32 + li;                              // this lane's column inside the workgroup span
-  const int px_l = col / C, c_l = col - px_l * C;
-#pragma unroll
-  for (int jb = 0; jb < 4; ++jb) {
-    const int rw0 = r0 + 32 * jb;
-    if (rw0 >= R) break;                                       // uniform over the workgroup
-    const int nrow = min(32, R - rw0);
-    if (jb) __syncthreads();                                   // the previous block has been read out
-#pragma unroll
-    for (int q = 0; q < 16; ++q) tt[px_l * RUN + ((q & 3) + 8 * (q >> 2) + 4 * kk) * C + c_l] = acc[jb][q];
-    __syncthreads();
-    if (nrow == 32 && ((R * C) & 3) == 0) {
-      for (int f = tid; f < PXW * 8 * C; f += NTH) {
-        const int px = f / (8 * C), w4 = f - px * 8 * C;
-        const int sp = s0 + px;
-        if (sp < S) *reinterpret_cast<float4*>(yi + ((size_t)sp * R + rw0) * C + 4 * w4) = *reinterpret_cast<const float4*>(tt + px * RUN + 4 * w4);
+        const int tail = (off + wcols) - p_full_hi * C;        // channels of the last, partial column
+        if (part == 1 && tail > 0) {
+          const int e = ln;
+          if (e < 32 * tail) {
+            const int r = e >> (tail - 1), c = e & (tail - 1);
+            yi[(size_t)obase + (size_t)p_full_hi * R * C + r * C + c] = tt[p_full_hi * RUN + r * C + c];
+          }
+        }
       }
     } else {
-      for (int e = tid; e < PXW * 32 * C; e += NTH) {
-        const int px = e / (32 * C), rem = e - px * 32 * C;
-        const int r = rem / C;
-        const int sp = s0 + px;
-        if (sp < S && r < nrow) yi[((size_t)sp * R + rw0) * C + rem] = tt[px * RUN + rem];
+      const int lo = off, hi = off + wcols;                    // tile columns in slot coordinates
+      constexpr int per = (G::SLOTS * 32 * C / 64 + 4) / 4;    // rounds of 64 elements per part
+#pragma unroll 1
+      for (int k = part * per; k < (part + 1) * per; ++k) {
+        const int e = ln + 64 * k;
+        const int p = e / (32 * C), rem = e - p * 32 * C, r = rem / C, cq = p * C + rem % C;
+        if (p < G::SLOTS && cq >= lo && cq < hi && r < nrow) yi[((size_t)(px0 + p) * R + rw0) * C + rem] = tt[p * RUN + rem];
       }
     }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  const float* tzl = tz + kBtPadLo + kk - li;
+  const float* wbl = wb + kk * WS + li;
+  auto fetch = [&](BandFrag& f, int s) {
+    const float* bb = wbl + ((s >> 2) & 1) * 32 * WS + (s & 3) * 8 * WS;
+    const float* ta = tzl + 8 * s;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) f.b[u] = bb[2 * u * WS];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) f.a[jb][u] = ta[2 * u - 32 * jb];
+  };
+  auto compute = [&](const BandFrag& f, int s) {
+    const int s8 = 8 * s;
+    if (k0 + s8 + 8 <= 0 || k0 + s8 >= R) return;              // the whole stage lies outside the image
+    bool on[4];
+#pragma unroll
+    for (int jb = 0; jb < 4; ++jb) on[jb] = s8 + 8 > 32 * jb && s8 < 32 * jb + L && r0 + 32 * jb < R;
+#define BAND_U(u) band_mfma<0>(f.a[0][u], f.b[u]); band_mfma<1>(f.a[1][u], f.b[u]); band_mfma<2>(f.a[2][u], f.b[u]); band_mfma<3>(f.a[3][u], f.b[u]);
+#define BAND_J(jb) if (on[jb]) { band_mfma<jb>(f.a[jb][0], f.b[0]); band_mfma<jb>(f.a[jb][1], f.b[1]); band_mfma<jb>(f.a[jb][2], f.b[2]); band_mfma<jb>(f.a[jb][3], f.b[3]); }
+    if (on[0] && on[1] && on[2] && on[3]) {                    // k-pair major: consecutive MFMAs go to different accumulators
+      BAND_U(0) BAND_U(1) BAND_U(2) BAND_U(3)
+    } else {
+      BAND_J(0) BAND_J(1) BAND_J(2) BAND_J(3)
+    }
+#undef BAND_U
+#undef BAND_J
+  };
+  lstore(ci_lo);
+  if (ci_lo + 1 < ci_hi) gload(ci_lo + 1);
+  BandFrag X, Y;
+  fetch(X, 4 * ci_lo);
+  const int c_done = (L + 7) / 8 - 1;                          // row block jb is complete after stage 4 jb + c_done, i.e. with
+  auto done_chunk = [&](int jb) { return min((4 * jb + c_done) >> 2, ci_hi - 1); };   // this chunk (or with the image)
+  // A row block's tile is written one chunk after its band ended, behind the loader's LDS write, into the CURRENT chunk's
+  // buffer (its last operands are in registers by then, and the loader overwrites it one chunk later), and drains from there
+  // a quarter per stage.  The bands end one chunk apart, so at most one block is draining, except in the last chunk,
+  // where the blocks the image cut short end together: those leave after the loop.
+  int dj = -1;                                                 // the draining row block
+  const float* dt = wb;
+  for (int ci = ci_lo; ci < ci_hi; ++ci) {
+    const int s = 4 * ci;
+    fetch(Y, s + 1);
+    compute(X, s);
+    if (dj >= 0) drain(dj, dt, 2);
+    fetch(X, s + 2);
+    compute(Y, s + 1);
+    if (dj >= 0) { drain(dj, dt, 3); dj = -1; }
+    fetch(Y, s + 3);
+    compute(X, s + 2);
+    if (ci + 1 < ci_hi) lstore(ci + 1);                        // the next chunk lands in the buffer chunk ci - 1 has left
+    for (int jb = 0; jb < 4; ++jb)
+      if (r0 + 32 * jb < R && done_chunk(jb) == ci - 1) {      // ci - 1 < ci_hi - 1: one block at most
+#ifdef BLUR_BAND_STAMP
+        if (jb == 0) st1 = __builtin_amdgcn_s_memtime();
+#endif
+        dj = jb;
+        dt = wb + (ci & 1) * 32 * WS;
+        tile_write(jb, wb + (ci & 1) * 32 * WS);
+        drain(dj, dt, 0);
+      }
+    if (ci + 2 < ci_hi) gload(ci + 2);
+    fetch(X, s + 4);                                           // past the last chunk: stale values nobody multiplies
+    compute(Y, s + 3);
+    if (dj >= 0) drain(dj, dt, 1);
   }
+  if (dj >= 0) { drain(dj, dt, 2); drain(dj, dt, 3); }
+  for (int jb = 0; jb < 4; ++jb)
+    if (r0 + 32 * jb < R && done_chunk(jb) == ci_hi - 1) {
+      float* tt = wb + (jb & 1) * 32 * WS;
+      tile_write(jb, tt);
+#pragma unroll 1
+      for (int part = 0; part < 4; ++part) drain(jb, tt, part);
+    }
+#ifdef BLUR_BAND_STAMP
+  if (lane == 0 && blockIdx.x * G::NW + wave < 4096) {
+    unsigned long long* d = g_band_dbg + (size_t)(blockIdx.x * G::NW + wave) * 4;
+    d[0] = st0; d[1] = st1; d[2] = __builtin_amdgcn_s_memtime();
+    d[3] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)) |             // HW_ID
+           ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) << 32);       // XCC_ID
+  }
+#endif
 }
+#ifdef BLUR_BAND_STAMP
+extern "C" int bg_dbg_band_read(unsigned long long* host, size_t n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_band_dbg), n * 8); }
+#endif
 
 template <int C>
 void launch_band_t(hipStream_t s, const float* src, float* dst, int B, int R, int S, const float* taps, int T) {
   using G = BandCfg<C>;
   const int cgs = (int)bg::cdiv(S, G::PXW), rgs = (int)bg::cdiv(R, kBtRows);
-  const size_t lds = ((size_t)((T + 2 * kBtPad + 3) & ~3) + G::BUF) * sizeof(float);
-  auto kern = blur_band_t_kernel<C>;
-  hipLaunchKernelGGL(kern, dim3((unsigned)((size_t)B * rgs * cgs)), dim3(G::NTH), lds, s, src, dst, R, S, rgs, cgs, taps, T);
+  const size_t lds = ((size_t)band_tz_floats(T) + G::BUF) * sizeof(float);
+  const dim3 grid((unsigned)((size_t)B * rgs * cgs));
+  const bool off32 = (size_t)R * S * C < ((size_t)1 << 29);    // 32-bit byte offsets per image
+  const int ld = !off32 ? 0 : (((S * C) & 3) == 0 && ((uintptr_t)src & 15) == 0) ? 2 : 1;
+  auto kern = ld == 2 ? blur_band_t_kernel<C, 2> : ld == 1 ? blur_band_t_kernel<C, 1> : blur_band_t_kernel<C, 0>;
+  hipLaunchKernelGGL(kern, grid, dim3(G::NTH), lds, s, src, dst, R, S, rgs, cgs, taps, T);
 }
 
 // ------------------------------------------------------------------------------------------------

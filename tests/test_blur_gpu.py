@@ -31,6 +31,11 @@ def _run(x, std):
     # not a multiple of 16 / 32, widths that end in a partial strip, more images than XCDs and fewer
     ((2, 256, 256, 3), 5.0), ((1, 256, 256, 3), 10.5), ((1, 256, 256, 3), 5.4), ((11, 72, 40, 1), 5.0), ((3, 300, 260, 3), 4.0),
     ((2, 66, 100, 3), 0.05), ((9, 130, 68, 3), 2.0), ((2, 257, 96, 1), 10.0), ((1, 90, 28, 1), 1.0),
+    # band passes above 65 taps with wave-private tiles: a ragged last column group, tiles that start / end inside a pixel
+    # (3 channels), row groups that end in a partial 32-row block, 1 / 3 / 4 channels
+    ((2, 200, 140, 3), 23.5), ((1, 136, 150, 4), 20.0), ((2, 150, 260, 1), 30.0), ((1, 72, 332, 3), 12.0), ((1, 330, 68, 3), 42.0),
+    # widths / heights whose rows are not float4-addressable in one pass, the other, or both (dword chunk loads, scalar stores)
+    ((2, 256, 250, 3), 23.5), ((2, 250, 256, 3), 23.5), ((1, 250, 250, 3), 23.5), ((2, 150, 131, 1), 30.0), ((1, 133, 140, 2), 20.0),
 ])
 def test_blur_matches_oracle(shape, std):
     rng = np.random.default_rng(0)

@@ -12,7 +12,11 @@ from blurred_gan_amd import ops  # noqa: E402
 
 def main():
     print(f"{'shape':<22}{'sigma':>7}{'taps':>6}{'ms':>9}{'GB/s(alg)':>11}{'%HBM':>7}{'TFLOP/s':>9}  kernels")
-    for (B, H, W, C), sigmas in (((256, 64, 64, 3), (5.0,)), ((128, 128, 128, 3), (5.0,)), ((64, 256, 256, 3), (5.0, 23.5, 42.34))):
+    cases = (((256, 64, 64, 3), (5.0,)), ((128, 128, 128, 3), (5.0,)), ((64, 256, 256, 3), (5.0, 23.5, 42.34)))
+    if "--extra" in sys.argv:       # the band passes at other channel counts, a ragged width and a width that is not float4-addressable
+        cases += (((64, 256, 256, 1), (23.5,)), ((64, 256, 256, 4), (5.0, 23.5)), ((64, 256, 256, 2), (23.5,)), ((64, 250, 250, 3), (23.5,)),
+                  ((16, 512, 512, 3), (23.5,)))
+    for (B, H, W, C), sigmas in cases:
         x = torch.rand(B, H, W, C, device="cuda") * 2 - 1
         y = torch.empty_like(x)
         for sg in sigmas:
