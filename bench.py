@@ -164,13 +164,15 @@ def bench_blur(args):
     for _ in range(3):
         step()
     torch.cuda.synchronize()
-    recs = ops.prof_records()
+    recs = ops.prof_records(with_exec=True)
     ops.prof_enable(False)
     ops.prof_reset()
     kern = {}
-    for name, ms, fl, by in recs:
+    exec_fl = 0.0
+    for name, ms, fl, by, ex in recs:
         k = kern.setdefault(name, [0, 0.0])
         k[0] += 1; k[1] += ms
+        exec_fl += ex if name.startswith("blur_band") else 0.0
     total_ms = sum(k[1] for k in kern.values())
     per_app_ms = total_ms / (3 * apps)
     ach = alg_bytes / (per_app_ms * 1e-3) / 1e9
@@ -180,6 +182,13 @@ def bench_blur(args):
             "traffic": hbm_traffic(f"blur{nt}", "blur256", B), "algorithmic_bytes_per_launch": round(alg_bytes),
             "launches_per_application": len(recs) // (3 * apps), "avg_application_ms": round(per_app_ms, 5),
             "kernels_ms_per_application": {n: round(k[1] / (3 * apps), 5) for n, k in kern.items()}}
+    if exec_fl > 0:
+        # above 65 taps the two transposing band passes run the banded Toeplitz product on the fp32 matrix pipe and THAT is the
+        # binding roof: the flops the passes issue (every 32x32x2 MFMA of the bands, image-clipped) over their own durations
+        tf = exec_fl / (total_ms * 1e-3) / 1e12
+        roof["mfma"] = {"bound": "mfma", "achieved": round(tf, 1), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+                        "frac": round(tf / PEAK_MFMA_F32_TFLOPS, 4), "issued_gflop_per_application": round(exec_fl / (3 * apps) / 1e9, 3),
+                        "time_at_peak_ms_per_application": round(exec_fl / (3 * apps) / (PEAK_MFMA_F32_TFLOPS * 1e12) * 1e3, 5)}
     if dist.rank() == 0:
         out = {"metric": "blur GB/s (8*H*W*C bytes per image per application, 7 applications per step)", "value": round(value, 1),
                "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 4),

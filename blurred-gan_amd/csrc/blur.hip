@@ -182,6 +182,9 @@ __global__ __launch_bounds__(kMfmaBlurThreads) void blur_mfma_kernel(const float
 // (traffic 2x algorithmic), restricted to the BAND: an output block of 32 rows only contracts over the source rows
 // within half a kernel of it.
 // ------------------------------------------------------------------------------------------------
+#ifndef BLUR_ST_AUX          // cache policy of the fused (cols / strip) kernels' float4 stores
+#define BLUR_ST_AUX 0
+#endif
 // cache policy of the band passes' float4 stores: 2 = nt (streamed; 97 against 100 us at 143 taps with the default policy)
 #ifndef BAND_ST_AUX
 #define BAND_ST_AUX 2
@@ -496,6 +499,25 @@ __global__ __launch_bounds__(BandCfg<C>::NTH, 3) void blur_band_t_kernel(const f
 extern "C" int bg_dbg_band_read(unsigned long long* host, size_t n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_band_dbg), n * 8); }
 #endif
 
+// Flops one band pass issues on the matrix pipe: 4 MFMAs of 32x32x2 for every (row block, 8-row stage) pair the kernel visits
+// -- the stages of rows [32 jb, 32 jb + 32 + T - 1) relative to r0 - T/2 that are not wholly outside the image -- for every
+// 32-float column tile that holds source columns.  (Same predicates as `compute` in the kernel.)
+static double band_exec_flops(int B, int R, int S, int C, int T) {
+  const int half = T >> 1, L = 32 + T - 1;
+  const long tiles = ((long)S * C + 31) / 32;
+  long pairs = 0;
+  for (int r0 = 0; r0 < R; r0 += kBtRows) {
+    const int k0 = r0 - half, k_end = std::min(R, r0 + kBtRows + half);
+    const int ci_lo = k0 < 0 ? (-k0) >> 5 : 0, ci_hi = (k_end - k0 + 31) >> 5;
+    for (int st = 4 * ci_lo; st < 4 * ci_hi; ++st) {
+      const int s8 = 8 * st;
+      if (k0 + s8 + 8 <= 0 || k0 + s8 >= R) continue;
+      for (int jb = 0; jb < 4; ++jb) pairs += (s8 + 8 > 32 * jb && s8 < 32 * jb + L && r0 + 32 * jb < R) ? 1 : 0;
+    }
+  }
+  return (double)B * tiles * pairs * 4.0 * (2.0 * 32 * 32 * 2);
+}
+
 template <int C>
 void launch_band_t(hipStream_t s, const float* src, float* dst, int B, int R, int S, const float* taps, int T) {
   using G = BandCfg<C>;
@@ -743,12 +765,12 @@ __global__ __launch_bounds__(256, BLUR_COLS_WPS) void blur_cols_kernel(const flo
 #pragma unroll
         for (int f = 0; f < 3; ++f)
           __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, make_float4(v[4 * f], v[4 * f + 1], v[4 * f + 2], v[4 * f + 3])), rsy,
-                                                 base == kOob ? kOob : base + 16 * f, 0, 0);
+                                                 base == kOob ? kOob : base + 16 * f, 0, BLUR_ST_AUX);
       } else {
 #pragma unroll
         for (int p = 0; p < 3; ++p) {
           const int q = p0 + 16 * p + 4 * g;
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc[p]), rsy, (row < H && q < W) ? (row * WC + q) * 4 : kOob, 0, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4, acc[p]), rsy, (row < H && q < W) ? (row * WC + q) * 4 : kOob, 0, BLUR_ST_AUX);
         }
       }
     }
@@ -967,7 +989,7 @@ __global__ __launch_bounds__(256) void blur_strip_kernel(const float* __restrict
             const bool ok = row < H && q < WC;
 #endif
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((__vector_size__(4 * sizeof(unsigned)))) unsigned, acc[t]), rsy,
-                                                   ok ? (row * WC + q) * 4 : kOob, 0, 0);
+                                                   ok ? (row * WC + q) * 4 : kOob, 0, BLUR_ST_AUX);
           }
         }
       };
@@ -1275,6 +1297,7 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
           case 3: launch_band_t<3>(s, src, dst, B, R, S, taps_d, n_taps); break;
           default: launch_band_t<4>(s, src, dst, B, R, S, taps_d, n_taps); break;
         }
+        L.exec_flops(band_exec_flops(B, R, S, C, n_taps));
         int rc = L.done("blur_band_t_kernel");
         if (rc) return rc;
       }
