@@ -361,7 +361,7 @@ __global__ __launch_bounds__(BandCfg<C>::NTH, 3) void blur_band_t_kernel(const f
     for (int q = 0; q < 16; ++q) td[((q & 3) + 8 * (q >> 2)) * C] = a[q];
   };
   // One quarter (part 0..3) of the read-out of row block jb's tile: a row block drains over the four stages after its tile
-  // was written, so that the waves of the launch, which run in step, do not all write a whole block at the same moment.
+  // was written, so that the stores of a block are spread over the band instead of leaving in one burst.
   // (Knock-out builds price the stores at 19 of 101 us at 143 taps, 10 of them the float4 store instructions themselves;
   // spreading them changed nothing measurable, the streaming cache policy 3 us.)
   auto drain = [&](int jb, const float* tt, int part) {
