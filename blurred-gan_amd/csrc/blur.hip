@@ -525,7 +525,8 @@ void launch_band_t(hipStream_t s, const float* src, float* dst, int B, int R, in
   const size_t lds = ((size_t)band_tz_floats(T) + G::BUF) * sizeof(float);
   const dim3 grid((unsigned)((size_t)B * rgs * cgs));
   const bool off32 = (size_t)R * S * C < ((size_t)1 << 29);    // 32-bit byte offsets per image
-  const int ld = !off32 ? 0 : (((S * C) & 3) == 0 && ((uintptr_t)src & 15) == 0) ? 2 : 1;
+  int ld = !off32 ? 0 : (((S * C) & 3) == 0 && ((uintptr_t)src & 15) == 0) ? 2 : 1;
+  if (const char* f = getenv("BG_BLUR_BAND_LD")) ld = std::min(ld, std::max(0, atoi(f)));    // test aid: force a slower loader (read per call)
   auto kern = ld == 2 ? blur_band_t_kernel<C, 2> : ld == 1 ? blur_band_t_kernel<C, 1> : blur_band_t_kernel<C, 0>;
   hipLaunchKernelGGL(kern, grid, dim3(G::NTH), lds, s, src, dst, R, S, rgs, cgs, taps, T);
 }

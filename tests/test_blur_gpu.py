@@ -47,6 +47,17 @@ def test_blur_matches_oracle(shape, std):
     np.testing.assert_allclose(y, ref, rtol=POINT_RTOL, atol=POINT_ATOL * 4)
 
 
+@pytest.mark.parametrize("ld", ["0", "1"])
+@pytest.mark.parametrize("shape,std", [((2, 200, 140, 3), 23.5), ((1, 136, 152, 4), 20.0), ((2, 150, 260, 1), 30.0)])
+def test_band_passes_slower_loaders(shape, std, ld, monkeypatch):
+    """The band passes' fallback chunk loaders -- dword buffer loads (1) and the synchronous 64-bit path kept for images beyond
+    32-bit byte offsets (0) -- forced on shapes that would take the float4 loader."""
+    monkeypatch.setenv("BG_BLUR_BAND_LD", ld)
+    x = np.random.default_rng(3).uniform(-1, 1, size=shape).astype(np.float32)
+    y, _ = _run(x, std)
+    np.testing.assert_allclose(y, O.blur_images(x.astype(np.float64), std), rtol=POINT_RTOL, atol=POINT_ATOL * 4)
+
+
 def _random_blur_cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []
