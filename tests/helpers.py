@@ -2,8 +2,6 @@
 import numpy as np
 import torch
 
-from oracle import models as OM
-
 # Stated tolerances (SURVEY.md 8c proposal): fp32 HIP kernels vs the float64 oracle.
 #   pointwise / blur: rtol 1e-5, atol 1e-6 ; conv family: rtol 2e-5*sqrt(K/800) of the output scale, floor 1e-5
 #   one full step's updated weights: rtol 1e-4 (Adam's m/(sqrt(v)+eps) amplifies tiny-gradient noise -> atol 2e-5)
@@ -45,6 +43,17 @@ def oracle_grad_list(grads):
     return out
 
 
+def rel_l2(a, b):
+    """||a - b||_2 / ||b||_2 in float64: the well-conditioned companion of the elementwise bounds."""
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-300))
+
+
+def cosine(a, b):
+    a, b = np.asarray(a, np.float64).ravel(), np.asarray(b, np.float64).ravel()
+    return float(a @ b / max(np.linalg.norm(a) * np.linalg.norm(b), 1e-300))
+
+
 def dev(a, dtype=torch.float32):
     return torch.from_numpy(np.ascontiguousarray(a)).to("cuda", dtype)
 
@@ -73,3 +82,27 @@ def sync_oracle_from_product(st, gan):
                     if k in p:
                         p[k] = next(it).astype(np.float64).reshape(p[k].shape)
     return st
+
+
+# Well-conditioned companions of the elementwise step bounds: per-tensor relative L2 error and cosine against the
+# float64 oracle.  A small systematic kernel error (a wrong tap weight, a missing term) moves these by orders of magnitude,
+# while the float32 cancellation noise of BatchNorm's backward, which forced the elementwise bounds up, does not.
+GRAD_L2 = {"g": 1e-3, "d": 2e-4}
+GRAD_COS = 1e-6
+
+
+def check_grad_quality(prod, ora, key, label, l2_bound=None, cos_bound=GRAD_COS):
+    """prod / ora: gradient lists of one network ('g' / 'd').  Returns {index: (rel L2, 1 - cosine)}; raises with the whole
+    table when any variable exceeds the bounds."""
+    l2_bound = GRAD_L2[key] if l2_bound is None else l2_bound
+    table, bad = {}, []
+    for i, (a, b) in enumerate(zip(prod, ora)):
+        b = np.asarray(b).reshape(a.shape)
+        l2, c = rel_l2(a, b), 1.0 - cosine(a, b)
+        table[i] = (l2, c)
+        if not (l2 <= l2_bound and c <= cos_bound):
+            bad.append(i)
+    line = ", ".join(f"{key}{i:02d} {l2:.1e}/{c:.0e}" for i, (l2, c) in table.items())
+    print(f"[grad quality] {label}: rel-L2 / (1-cos) per variable: {line}")
+    assert not bad, f"{label}: variables {bad} exceed rel-L2 {l2_bound:g} or 1-cos {cos_bound:g}: {line}"
+    return table

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import step as S
-from helpers import load_oracle_weights, product_grads, product_slots, oracle_grad_list, oracle_weight_list
+from helpers import load_oracle_weights, product_grads, product_slots, oracle_grad_list, oracle_weight_list, check_grad_quality, rel_l2
 
 pytestmark = pytest.mark.gpu
 
@@ -61,6 +61,9 @@ def test_gradients_match_oracle(arch, B, std):
     for a, b in zip(pgg, oracle_grad_list(gg)):
         scale = max(np.abs(b).max(), 1e-6)
         np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=g_atol * scale)
+    # the well-conditioned criterion beside the elementwise one: per-variable relative L2 error and cosine
+    check_grad_quality(pg, oracle_grad_list(dg), "d", f"{arch} B={B} critic")
+    check_grad_quality(pgg, oracle_grad_list(gg), "g", f"{arch} B={B} generator")
     np.testing.assert_allclose(gan.images[0].cpu().numpy(), fakes, rtol=1e-4, atol=1e-5)
     for k in ("real_scores", "disc_loss", "gp_term", "norm_term"):
         assert abs(got[k] - met[k]) < 1e-4 * max(1, abs(met[k])), (k, got[k], met[k])
@@ -137,6 +140,9 @@ def test_real_architecture_training_steps_match_oracle(arch, B, std, steps):
                     e = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
                     worst[key + "_" + slot] = max(worst.get(key + "_" + slot, 0.0), e)
                     assert e <= (1e-2 if key == "g" else 3e-3), (key, slot, a.shape, e, it)
+                    l2 = rel_l2(a, b)                       # ... and the per-tensor relative L2 error beside the elementwise bound
+                    worst[key + "_" + slot + "_l2"] = max(worst.get(key + "_" + slot + "_l2", 0.0), l2)
+                    assert l2 <= (2e-3 if key == "g" else 4e-4), (key, slot, a.shape, l2, it)
     print(f"{arch} B={B} {steps} steps: worst deviations {worst}")
 
 
@@ -162,6 +168,8 @@ def test_celeba64_batch256_step_matches_oracle():
     # its own float64 run already at batch 64
     for a, b in zip(product_grads(gan.generator), oracle_grad_list(gg)):
         np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=2e-2 * max(np.abs(b).max(), 1e-6))
+    check_grad_quality(product_grads(gan.discriminator), oracle_grad_list(dg), "d", "celeba64 B=256 critic")
+    check_grad_quality(product_grads(gan.generator), oracle_grad_list(gg), "g", "celeba64 B=256 generator")
     np.testing.assert_allclose(gan.images[0].cpu().numpy(), fakes, rtol=1e-4, atol=1e-5)
     for k in ("real_scores", "disc_loss", "gp_term", "norm_term"):
         assert abs(got[k] - met[k]) < 1e-4 * max(1, abs(met[k])), (k, got[k], met[k])
@@ -202,24 +210,49 @@ def test_training_reduces_critic_loss_own_rng():
     assert tuple(s.shape) == (B, 8, 8, 3) and torch.isfinite(s).all() and s.abs().max() <= 1.0
 
 
-def test_loss_curves_track_the_oracle_over_25_steps():
-    """Loss-curve parity (BASELINE.json: 'loss curves within tolerance of the CPU reference'): 25 consecutive steps with
-    injected randomness; every per-step metric of the HIP path stays within 1 % (+1e-3) of the float64 oracle's."""
-    arch, B = "tiny", 6
-    gan, st, reals, rng = _make(arch, B, 1.0, seed=21)
+@pytest.mark.parametrize("arch,B,std", [("tiny", 6, 1.0), ("mnist", 8, 0.05), ("celeba64", 8, 5.0)])
+def test_loss_curves_track_the_oracle_over_25_steps(arch, B, std):
+    """Loss-curve parity (BASELINE.json: 'loss curves within tolerance of the CPU reference'; the loop of wgan.py:86-114):
+    25 consecutive FREE-RUNNING steps with injected randomness -- the product, the float64 oracle and the float32 oracle each
+    carry their own weights, BN statistics and Adam slots forward; nothing is re-synchronised -- on the 8x8 test stack and on
+    the real MNIST and 64x64 stacks.
+
+    Criterion, per step t and metric k, e(t, k) = |metric - float64 oracle| / (|float64 oracle| + 0.1):
+        e_HIP(t, k) <= max(1e-2, 3 * max_{s <= t, j} e_float32-oracle(s, j)).
+    The plain 1 % bound alone is what the 8x8 stack is held to (and meets); at the real stacks it is not attainable by ANY
+    float32 implementation of this loop: the trajectory is chaotic at batch 8 (losses swing between -120 and +190 at
+    celeba64), and the ORACLE ITSELF run in float32 -- the reference's own precision, TF computes in float32 -- leaves its
+    float64 run by 2.1 % (mnist) and 3.7 % (celeba64) within 25 steps (measured on the CPU, oracle against oracle).  So the
+    test carries the float32 oracle along as the yardstick of the precision class and holds the HIP path to a small multiple
+    of ITS deviation; the first steps, where conditioning is still good, are effectively held to the 1 % bound."""
+    gan, st, reals, rng = _make(arch, B, std, seed=21)
+    st32 = copy.deepcopy(st)
+    for key in ("g", "d", "g_m", "g_v", "d_m", "d_v"):
+        st32[key] = [{k: v.astype(np.float32) for k, v in p.items()} for p in st32[key]]
     hp = dict(S.DEFAULT_HP, global_batch_size=B)
-    worst = 0.0
+    names = ("disc_loss", "gen_loss", "gp_term", "real_scores", "fake_scores")
+    worst, worst32, env32, curve, within_1pct = 0.0, 0.0, 0.0, [], 0
     for it in range(25):
         rnd = S.draw_randomness(arch, B, rng, np.float64)
         r = rng.uniform(-1, 1, size=reals.shape)
         st, met, _ = S.train_on_batch(st, r, rnd, hp)
+        rnd32 = {k: (v.astype(np.float32) if isinstance(v, np.ndarray) else v) for k, v in rnd.items()}
+        st32, met32, _ = S.train_on_batch(st32, r.astype(np.float32), rnd32, hp)
         got = dict(zip(gan.metrics_names, gan.train_on_batch(r.astype(np.float32), randomness=rnd)))
-        for k in ("disc_loss", "gen_loss", "gp_term", "real_scores", "fake_scores"):
-            err = abs(got[k] - met[k]) / (abs(met[k]) + 0.1)
-            worst = max(worst, err)
-            assert err < 1e-2, (it, k, got[k], met[k])
+        e_hip = max(abs(got[k] - met[k]) / (abs(met[k]) + 0.1) for k in names)
+        e_32 = max(abs(met32[k] - met[k]) / (abs(met[k]) + 0.1) for k in names)
+        env32 = max(env32, e_32)
+        worst, worst32 = max(worst, e_hip), max(worst32, e_32)
+        within_1pct += e_hip < 1e-2
+        curve.append((it, round(met["disc_loss"], 3), round(got["disc_loss"], 3), round(met["gen_loss"], 3), round(got["gen_loss"], 3),
+                      f"{e_hip:.1e}", f"{e_32:.1e}"))
+        assert e_hip <= max(1e-2, 3.0 * env32), (arch, it, e_hip, env32, curve)
+    print(f"{arch} B={B}: (step, disc_loss oracle64 / HIP, gen_loss oracle64 / HIP, deviation HIP, deviation float32 oracle):", curve)
+    print(f"{arch} B={B}: worst deviation over 25 free-running steps: HIP {worst:.2e}, float32 oracle {worst32:.2e}; "
+          f"steps with HIP inside the plain 1 % bound: {within_1pct}/25")
     assert int(gan.n_batches) == 25
-    print("worst relative metric deviation over 25 steps:", worst)
+    if arch == "tiny":
+        assert worst < 1e-2
 
 
 def test_resume_from_checkpoint_equals_uninterrupted_run(tmp_path):
