@@ -92,7 +92,31 @@ def cpu_baseline(arch, batch, sigma, seconds_budget=30.0):
                       f"{torch.get_num_threads()} threads, autograd double backward for the penalty)"}
 
 
-TRAFFIC_FILE = "profiles/r02_hbm_traffic.json"
+def cpu_baseline_blur(B, H, W, C, sigma, apps, seconds_budget=15.0):
+    """The blur alone on the host cores: oracle/torch_ref.blur, i.e. the two SAME depthwise convolutions of
+    gaussian_blur.py:116-130 as torch-CPU grouped convs (the closest stand-in for TF's depthwise_conv2d on the CPU), on a
+    BOUNDED sample of the same workload: whole applications over the same 64 images until the budget is spent.
+    Reported in the line's own unit (algorithmic GB/s, 8*H*W*C bytes per image per application), not a target."""
+    from oracle import torch_ref
+    gen = torch.Generator().manual_seed(0)
+    sb = B
+    x = torch.rand(sb, H, W, C, generator=gen) * 2 - 1
+    with torch.no_grad():
+        torch_ref.blur(x[:1], sigma)                      # warm-up (oneDNN primitive creation)
+        n, t0 = 0, time.time()
+        while True:
+            torch_ref.blur(x, sigma)
+            n += 1
+            if time.time() - t0 > seconds_budget or n >= 20 * apps:
+                break
+    dt = time.time() - t0
+    return {"value": round(8.0 * sb * H * W * C * n / dt / 1e9, 4), "unit": "GB/s", "cores": torch.get_num_threads(), "kind": "port",
+            "cpu": cpu_model(), "host_cpus": os.cpu_count(),
+            "sample": f"{n} application(s) of the blur on {sb} of the {B} images ({sb}x{H}x{W}x{C}) in {dt:.1f} s (oracle/torch_ref.blur: two "
+                      f"depthwise torch-CPU convs, fp32, {torch.get_num_threads()} threads)"}
+
+
+TRAFFIC_FILE = "profiles/hbm_traffic.json"      # refreshed by tools/pmc_step.sh + tools/traffic_update.py; a per-round copy is kept as rNN_hbm_traffic.json
 
 
 def hbm_traffic(kernel, arch, batch):
@@ -199,6 +223,8 @@ def bench_blur(args):
                "config": {"workload": f"blur256: {B}x{H}x{W}x{C} per GPU, sigma {args.sigma} ({nt} taps), {apps} blur applications per step",
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_blur(B, H, W, C, args.sigma, apps)
         print(json.dumps(out), flush=True)
     dist.barrier()
     dist.shutdown()

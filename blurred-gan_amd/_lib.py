@@ -16,9 +16,10 @@ class BgError(RuntimeError):
 class Epilogue(C.Structure):
     _fields_ = [("mode", C.c_int), ("bias", C.c_void_p), ("ref", C.c_void_p), ("keep", C.c_void_p),
                 ("alpha", C.c_float), ("scale", C.c_float), ("splitk_ws", C.c_void_p), ("splitk_ws_bytes", C.c_size_t),
-                ("keep_elems", C.c_size_t), ("stats", C.c_void_p), ("stats_capacity", C.c_size_t)]
+                ("keep_elems", C.c_size_t), ("stats", C.c_void_p), ("stats_capacity", C.c_size_t), ("stats_rows", C.POINTER(C.c_int))]
 
 
+ABI_VERSION = 3           # include/bgan.h BG_ABI_VERSION
 EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_AFFINE_LRELU = 0, 1, 2, 3, 4
 
 _p, _i, _f, _z, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
@@ -38,7 +39,6 @@ SIGNATURES = {
     "bg_blur_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "bg_blur_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _p]),
     "bg_conv2d_splitk_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i]),
-    "bg_conv2d_stats_rows": (_i, []),
     "bg_conv2d_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
     "bg_conv2d_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
     "bg_conv2d_bwd_filter_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i]),
@@ -100,8 +100,8 @@ def load():
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the .so lacks a declared symbol
         fn.restype, fn.argtypes = res, args
-    if lib.bg_version() != 2:
-        raise BgError(f"ABI version mismatch: library {lib.bg_version()}, binding 2")
+    if lib.bg_version() != ABI_VERSION:
+        raise BgError(f"ABI version mismatch: library {lib.bg_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 

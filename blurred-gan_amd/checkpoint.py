@@ -10,11 +10,15 @@ from __future__ import annotations
 
 import json
 import os
+import re
 
 import numpy as np
 import torch
 
 INDEX = "checkpoint"
+
+
+_CKPT_NAME = re.compile(r"^ckpt-\d+\.npz$")
 
 
 class CheckpointManager:
@@ -37,7 +41,7 @@ class CheckpointManager:
         if names is None:
             if not os.path.isdir(self.directory):
                 return []
-            names = [n for n in os.listdir(self.directory) if n.startswith("ckpt-") and n.endswith(".npz")]
+            names = [n for n in os.listdir(self.directory) if _CKPT_NAME.match(n)]      # never the ckpt-N.npz.tmp.npz of a crashed save
             names.sort(key=lambda n: os.path.getmtime(os.path.join(self.directory, n)))
         return [n for n in names if os.path.exists(os.path.join(self.directory, n))]
 
@@ -81,6 +85,12 @@ class CheckpointManager:
         name = f"ckpt-{n}.npz"
         path = os.path.join(self.directory, name)
         tmp = path + ".tmp.npz"
+        for stale in os.listdir(self.directory):                     # temp files a crashed save left behind
+            if stale.endswith(".tmp.npz") and stale.startswith("ckpt-"):
+                try:
+                    os.remove(os.path.join(self.directory, stale))
+                except OSError:
+                    pass
         np.savez(tmp, **self.state_dict())
         os.replace(tmp, path)                   # a crash mid-write never leaves a truncated "latest" checkpoint
         names = [x for x in self._read_index() if x != name] + [name]

@@ -22,7 +22,6 @@ struct GatherPhase {
   int tap[kMaxTaps];   // (dy+64) | (dx+64)<<8 | wi<<16
 };
 
-extern thread_local int g_conv_stats_rows;   // conv_igemm.hip
 
 struct GatherParams {
   const float* A;      // [B][Hs][Ws][Ck]

@@ -18,7 +18,6 @@
 #include <cstdlib>
 
 namespace bg {
-thread_local int g_conv_stats_rows = 0;      // rows of bg_epilogue.stats written by this thread's last conv call
 }
 
 namespace {
@@ -869,10 +868,10 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
     // BatchNorm statistics in the epilogue: plain stores only (no split-K slabs, no bias / activation), one row per workgroup
     const size_t srows = (size_t)(p.nphase / p.pmerge) * p.mtiles;
     constexpr bool has_stats_variant = (BM == 64 && BN == 64) || (BM == 128 && BN == 32);     // the tiles the default plan picks
-    const bool st_ok = has_stats_variant && epi && epi->stats && ks == 1 && p.epi_mode == BG_EPI_NONE && !p.bias &&
+    const bool st_ok = has_stats_variant && epi && epi->stats && epi->stats_rows && ks == 1 && p.epi_mode == BG_EPI_NONE && !p.bias &&
                        epi->stats_capacity >= srows * 2 * (size_t)p.N;
     p.stats = st_ok ? epi->stats : nullptr;
-    bg::g_conv_stats_rows = st_ok ? (int)srows : 0;
+    if (st_ok) *epi->stats_rows = (int)srows;
     bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
     if (L.prof) L.exec_flops(gather_exec_flops(p, BM, BN));
     if constexpr (has_stats_variant) {
@@ -1065,7 +1064,7 @@ size_t bg_conv2d_splitk_workspace_bytes(int bwd_data, int B, int H, int W, int C
 
 int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int W, int Cin, int Cout, int ksize,
                   int stride, const bg_epilogue* epi, void* stream) {
-  bg::g_conv_stats_rows = 0;
+  if (epi && epi->stats_rows) *epi->stats_rows = 0;
   int rc = check_conv_args("bg_conv2d_fwd", x, wT_d, y, B, H, W, Cin, Cout, ksize, stride);
   if (rc) return rc;
   int taken = 0;
@@ -1084,7 +1083,7 @@ int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int
 
 int bg_conv2d_bwd_data(const float* dy, const float* w_d, float* dx, int B, int H, int W, int Cin, int Cout, int ksize,
                        int stride, const bg_epilogue* epi, void* stream) {
-  bg::g_conv_stats_rows = 0;
+  if (epi && epi->stats_rows) *epi->stats_rows = 0;
   int rc = check_conv_args("bg_conv2d_bwd_data", dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride);
   if (rc) return rc;
   int taken = 0;
@@ -1118,7 +1117,5 @@ int bg_transpose_last2_batched(const float* src_base, float* dst_base, const int
                      reinterpret_cast<const TransposeDesc*>(desc_d), n);
   return L.done("transpose_batched_kernel");
 }
-
-int bg_conv2d_stats_rows(void) { return bg::g_conv_stats_rows; }
 
 }  // extern "C"

@@ -32,17 +32,26 @@ def collectives_active():
 
 
 def local_rank():
-    """Device index of this process: LOCAL_RANK, one process per GPU.  More local ranks than visible devices is an error (two
-    RCCL ranks on one card hang inside the first collective instead of failing) unless the rehearsal switch
-    BGAN_DIST_SHARE_DEVICES=1 or the gloo backend override is set: then ranks share devices round-robin (tests/test_dp_gpu.py)."""
+    """Device index of this process (one process per GPU).
+
+    * LOCAL_RANK < visible devices: that device (torchrun on a whole node).
+    * exactly ONE visible device and a per-rank mask in the environment (ROCR_VISIBLE_DEVICES / HIP_VISIBLE_DEVICES /
+      CUDA_VISIBLE_DEVICES, e.g. SLURM --gpus-per-task=1): device 0 -- every rank sees its own card as the only one.
+    * anything else with more local ranks than devices is an error: two RCCL ranks on one card hang inside the first
+      collective instead of failing.  Sharing a card round-robin is a REHEARSAL mode and needs the gloo backend
+      (BGAN_DIST_BACKEND=gloo, with or without BGAN_DIST_SHARE_DEVICES=1); BGAN_DIST_SHARE_DEVICES=1 with the RCCL backend is
+      refused for the same reason."""
     lr = int(os.environ.get("LOCAL_RANK", "0"))
     n = torch.cuda.device_count() if torch.cuda.is_available() else 0
     if n > 0 and lr >= n:
-        if os.environ.get("BGAN_DIST_SHARE_DEVICES") == "1" or os.environ.get("BGAN_DIST_BACKEND") == "gloo":
+        if os.environ.get("BGAN_DIST_BACKEND") == "gloo":
             return lr % n
+        masked = any(os.environ.get(v) for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"))
+        if n == 1 and masked and os.environ.get("BGAN_DIST_SHARE_DEVICES") != "1":
+            return 0
         raise RuntimeError(f"LOCAL_RANK={lr} but only {n} GPU(s) are visible: launch one process per GPU "
-                           f"(--nproc-per-node <= {n}); set BGAN_DIST_SHARE_DEVICES=1 with BGAN_DIST_BACKEND=gloo to rehearse "
-                           "several ranks on one card")
+                           f"(--nproc-per-node <= {n}), or mask one device per rank (ROCR_VISIBLE_DEVICES); to rehearse several "
+                           "ranks on one card set BGAN_DIST_BACKEND=gloo (RCCL ranks sharing a card hang in their first collective)")
     return lr
 
 

@@ -329,7 +329,7 @@ class Net:
                     ops.conv2d_fwd(xin, self.store.transposed_kernel(st.lin), tgt, st.lin.k, st.lin.stride, epi)
                 else:   # Conv2DTranspose forward == data-gradient of the conv with the same kernel array
                     ops.conv2d_bwd_data(xin, st.lin.vars["kernel"], tgt, st.lin.k, st.lin.stride, epi)
-                stat_rows = ops.conv2d_stats_rows() if (st.bn is not None and epi.stats) else 0
+                stat_rows = ops.conv2d_stats_rows(epi) if st.bn is not None else 0
             if st.bn is not None and not (st.kind != "dense" and not training and bias is None):
                 C = st.out_shape[-1]
                 M = tgt.numel() // C

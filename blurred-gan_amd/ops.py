@@ -73,6 +73,8 @@ def epilogue(mode=EPI_NONE, bias=None, ref=None, keep=None, alpha=LRELU_ALPHA, s
     e.keep_elems = int(keep_elems)
     e.stats = stats.data_ptr() if stats is not None else None
     e.stats_capacity = stats.numel() if stats is not None else 0
+    e._rows = C.c_int(0)                    # out: rows of `stats` the conv call wrote (conv2d_stats_rows(e))
+    e.stats_rows = C.pointer(e._rows) if stats is not None else None
     e.splitk_ws = ws.data_ptr() if ws is not None else None
     e.splitk_ws_bytes = ws.numel() * ws.element_size() if ws is not None else 0
     e.mode = mode
@@ -199,9 +201,10 @@ def bn_train_fwd(x, y, M, Cc, gamma, beta, moving_mean, moving_var, save_mean, s
     return y
 
 
-def conv2d_stats_rows():
-    """Rows of epilogue(stats=...) the last conv2d_fwd / conv2d_bwd_data call wrote (0: run the normal statistics pass)."""
-    return _lib.load().bg_conv2d_stats_rows()
+def conv2d_stats_rows(epi):
+    """Rows of epilogue(stats=...) that the conv2d_fwd / conv2d_bwd_data call given ``epi`` wrote (0: that geometry took a
+    kernel without the statistics epilogue -- run the normal statistics pass).  Returned through the call's own epilogue."""
+    return epi._rows.value if epi is not None and epi.stats else 0
 
 
 def bn_train_fwd_partials(partial, nrows, x, y, M, Cc, gamma, beta, moving_mean, moving_var, save_mean, save_inv, eps=1e-3, momentum=0.99,

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BG_ABI_VERSION 2
+#define BG_ABI_VERSION 3
 
 typedef enum {
   BG_OK = 0,
@@ -103,13 +103,12 @@ typedef struct {
                            * 0 = every element */
   float* stats;           /* optional (mode BG_EPI_NONE, no bias): the MFMA gather kernel also leaves per-workgroup column sums and
                            * sums of squares of what it stores -- partial[row][2][Cout] -- so that the BatchNormalization that
-                           * follows (demo_celeba.py:62-90) needs no statistics pass over the tensor; bg_conv2d_stats_rows() tells
-                           * how many rows the last call wrote (0: this geometry took another kernel, run the normal pass) */
+                           * follows (demo_celeba.py:62-90) needs no statistics pass over the tensor; `*stats_rows` tells how many
+                           * rows THIS call wrote (0: this geometry took another kernel, run the normal pass) */
   size_t stats_capacity;  /* floats available behind `stats` */
+  int* stats_rows;        /* HOST pointer, out (required when `stats` is set): rows of `stats` this call wrote.  Returned through
+                           * the call itself -- ABI 2 kept it in per-thread last-call state (bg_conv2d_stats_rows, removed in 3) */
 } bg_epilogue;
-
-/* rows of epi->stats written by this thread's last bg_conv2d_fwd / bg_conv2d_bwd_data call (0 = none) */
-int bg_conv2d_stats_rows(void);
 
 /* bytes of split-K scratch the forward (bwd_data = 0) / data-gradient (bwd_data = 1) call can use; 0 = never splits */
 size_t bg_conv2d_splitk_workspace_bytes(int bwd_data, int B, int H, int W, int Cin, int Cout, int ksize, int stride);

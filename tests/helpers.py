@@ -87,22 +87,56 @@ def sync_oracle_from_product(st, gan):
 # Well-conditioned companions of the elementwise step bounds: per-tensor relative L2 error and cosine against the
 # float64 oracle.  A small systematic kernel error (a wrong tap weight, a missing term) moves these by orders of magnitude,
 # while the float32 cancellation noise of BatchNorm's backward, which forced the elementwise bounds up, does not.
+#
+# Base bounds: relative L2 <= 1e-3 (generator) / 2e-4 (critic), cosine >= 1 - 1e-6.  Where a gradient is itself a small
+# residue of large cancelling terms no float32 evaluation meets a fixed bound -- measured on the CPU, the ORACLE run in float32
+# against its own float64 run at celeba64 / batch 64: generator 8e-4 ... 7e-3 (1 - cos up to 2e-5), critic <= 1.5e-5, the Dense
+# bias of the critic (sum of +-B/gbs + 1e-4 sign terms, a 1e-4-sized residue) 5.5e-4.  So a test may pass that float32 run as
+# the YARDSTICK of the precision class: the bound of a variable is then max(base, 3 x the float32 oracle's own deviation).
 GRAD_L2 = {"g": 1e-3, "d": 2e-4}
 GRAD_COS = 1e-6
+YARDSTICK = 3.0
 
 
-def check_grad_quality(prod, ora, key, label, l2_bound=None, cos_bound=GRAD_COS):
-    """prod / ora: gradient lists of one network ('g' / 'd').  Returns {index: (rel L2, 1 - cosine)}; raises with the whole
-    table when any variable exceeds the bounds."""
+def to_float32_state(st):
+    """Copy of an oracle state with every array in float32 (weights, BN statistics, Adam slots)."""
+    import copy
+    st32 = copy.deepcopy(st)
+    for key in ("g", "d", "g_m", "g_v", "d_m", "d_v"):
+        st32[key] = [{k: np.asarray(v).astype(np.float32) for k, v in p.items()} for p in st32[key]]
+    return st32
+
+
+def to_float32_randomness(rnd):
+    return {k: (v.astype(np.float32) if isinstance(v, np.ndarray) else v) for k, v in rnd.items()}
+
+
+def check_grad_quality(prod, ora, key, label, ora32=None, l2_bound=None, cos_bound=GRAD_COS):
+    """prod / ora: gradient lists of one network ('g' / 'd'), HIP path and float64 oracle; ora32: the float32 oracle's (the
+    yardstick, optional).  Returns {index: (rel L2, 1 - cosine)}; raises with the whole table when a variable exceeds
+    max(base bound, 3 x yardstick).  A variable whose float64 gradient is exactly zero must be (nearly) zero in the product."""
     l2_bound = GRAD_L2[key] if l2_bound is None else l2_bound
-    table, bad = {}, []
+    table, bad, cells = {}, [], []
     for i, (a, b) in enumerate(zip(prod, ora)):
-        b = np.asarray(b).reshape(a.shape)
+        b = np.asarray(b, np.float64).reshape(a.shape)
+        if not np.any(b):
+            ok = float(np.abs(a).max()) <= 1e-6
+            table[i] = (float(np.abs(a).max()), 0.0)
+            cells.append(f"{key}{i:02d} zero-gradient |a|max {table[i][0]:.1e}")
+            bad += [] if ok else [i]
+            continue
         l2, c = rel_l2(a, b), 1.0 - cosine(a, b)
+        lb, cb, y = l2_bound, cos_bound, ""
+        if ora32 is not None:
+            b32 = np.asarray(ora32[i], np.float64).reshape(a.shape)
+            l32, c32 = rel_l2(b32, b), 1.0 - cosine(b32, b)
+            lb, cb = max(lb, YARDSTICK * l32), max(cb, YARDSTICK * c32)
+            y = f" [f32 oracle {l32:.1e}/{c32:.0e}]"
         table[i] = (l2, c)
-        if not (l2 <= l2_bound and c <= cos_bound):
+        cells.append(f"{key}{i:02d} {l2:.1e}/{c:.0e}{y}")
+        if not (l2 <= lb and c <= cb):
             bad.append(i)
-    line = ", ".join(f"{key}{i:02d} {l2:.1e}/{c:.0e}" for i, (l2, c) in table.items())
+    line = ", ".join(cells)
     print(f"[grad quality] {label}: rel-L2 / (1-cos) per variable: {line}")
-    assert not bad, f"{label}: variables {bad} exceed rel-L2 {l2_bound:g} or 1-cos {cos_bound:g}: {line}"
+    assert not bad, f"{label}: variables {bad} exceed max(rel-L2 {l2_bound:g}, 1-cos {cos_bound:g}; {YARDSTICK:g} x float32 oracle): {line}"
     return table

@@ -282,7 +282,7 @@ def test_conv_epilogue_leaves_batchnorm_statistics(B, H, W, Ci, Co, s, bwd):
         ops.conv2d_bwd_data(src, wd, out, 5, s, epi)
     else:
         ops.conv2d_fwd(src, wT, out, 5, s, epi)
-    rows = ops.conv2d_stats_rows()
+    rows = ops.conv2d_stats_rows(epi)
     assert rows > 0, "this geometry is expected on the MFMA gather kernel without split-K"
     part = stats[:rows * 2 * N].view(rows, 2, N).double().cpu().numpy()
     assert np.isfinite(part).all(), "every partial row must have been written"
@@ -292,5 +292,6 @@ def test_conv_epilogue_leaves_batchnorm_statistics(B, H, W, Ci, Co, s, bwd):
     np.testing.assert_allclose(part[:, 1].sum(0), (flat ** 2).sum(0), rtol=1e-5, atol=1e-6)
     # a thin layer goes to another kernel family: no rows, the caller runs the normal statistics pass
     o2 = torch.empty(2, 16, 16, 3, device="cuda")
-    ops.conv2d_fwd(torch.rand(2, 16, 16, 32, device="cuda"), torch.rand(25 * 3 * 32, device="cuda"), o2, 5, 1, ops.epilogue(stats=stats))
-    assert ops.conv2d_stats_rows() == 0
+    epi2 = ops.epilogue(stats=stats)
+    ops.conv2d_fwd(torch.rand(2, 16, 16, 32, device="cuda"), torch.rand(25 * 3 * 32, device="cuda"), o2, 5, 1, epi2)
+    assert ops.conv2d_stats_rows(epi2) == 0 and ops.conv2d_stats_rows(epi) == rows      # per call, not last-call state

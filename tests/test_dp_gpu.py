@@ -198,8 +198,18 @@ def test_local_rank_beyond_visible_devices_is_an_error(monkeypatch):
     monkeypatch.delenv("BGAN_DIST_BACKEND", raising=False)
     with pytest.raises(RuntimeError, match="LOCAL_RANK"):
         dist.local_rank()
-    monkeypatch.setenv("BGAN_DIST_SHARE_DEVICES", "1")
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        monkeypatch.delenv(v, raising=False)
+    monkeypatch.setenv("BGAN_DIST_SHARE_DEVICES", "1")           # sharing a card under RCCL hangs: the switch alone is refused
+    with pytest.raises(RuntimeError, match="LOCAL_RANK"):
+        dist.local_rank()
+    monkeypatch.setenv("BGAN_DIST_BACKEND", "gloo")              # the rehearsal mode: gloo, ranks round-robin over the cards
     assert dist.local_rank() == 0
-    monkeypatch.setenv("LOCAL_RANK", "0")
+    monkeypatch.delenv("BGAN_DIST_BACKEND", raising=False)
     monkeypatch.delenv("BGAN_DIST_SHARE_DEVICES", raising=False)
+    if n == 1:                                                   # one masked device per rank (SLURM --gpus-per-task=1): device 0
+        monkeypatch.setenv("ROCR_VISIBLE_DEVICES", "3")
+        assert dist.local_rank() == 0
+        monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
+    monkeypatch.setenv("LOCAL_RANK", "0")
     assert dist.local_rank() == 0

@@ -168,6 +168,26 @@ def test_checkpoint_manager_orders_by_save_time_not_by_file_number(tmp_path):
     assert len(keep_all.checkpoints) == 7
 
 
+def test_checkpoint_manager_ignores_and_removes_temp_files_of_a_crashed_save(tmp_path):
+    """A save that died mid-write leaves ckpt-N.npz.tmp.npz behind; in a directory without a readable index it must not
+    become latest_checkpoint (it is the newest file there), and the next save() removes it."""
+    from blurred_gan_amd.checkpoint import CheckpointManager
+    bg.set_seed(5)
+    g, d = models.DCGANGenerator(arch="tiny"), models.DCGANDiscriminator(arch="tiny")
+    gan = bg.BlurredWGANGP(g, d, bg.BlurredWGANGP.HyperParameters(), bg.TrainingConfig())
+    mgr = CheckpointManager(gan, str(tmp_path / "c"))
+    mgr.save(10)
+    os.remove(mgr._index_path())                                       # index lost / written by hand
+    with open(tmp_path / "c" / "ckpt-20.npz.tmp.npz", "wb") as f:      # truncated temp file, newest in the directory
+        f.write(b"PK\x03\x04 truncated")
+    fresh = CheckpointManager(gan, str(tmp_path / "c"))
+    assert fresh.latest_checkpoint.endswith("ckpt-10.npz")
+    fresh.restore(fresh.latest_checkpoint)
+    fresh.save(30)
+    assert sorted(os.listdir(tmp_path / "c")) == ["checkpoint.json", "ckpt-10.npz", "ckpt-30.npz"] or \
+        not [n for n in os.listdir(tmp_path / "c") if n.endswith(".tmp.npz")]
+
+
 def test_feed_images_to_metric_callback_counts():
     class M:
         name = "m"

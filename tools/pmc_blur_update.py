@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Rewrites the blur256 entry of profiles/r02_hbm_traffic.json from tools/pmc_blur.sh outputs (gpurun_out/pmc_<tag>.json), tagging it
+"""Rewrites the blur256 entry of profiles/hbm_traffic.json from tools/pmc_blur.sh outputs (gpurun_out/pmc_<tag>.json), tagging it
 with the hash of the blur source they were taken on.  Usage: pmc_blur_update.py <taps>=<pmc json> [...]   e.g. 31=gpurun_out/pmc_f31.json"""
 import hashlib
 import json
@@ -7,7 +7,7 @@ import os
 import sys
 
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-path = os.path.join(root, "profiles", "r02_hbm_traffic.json")
+path = os.path.join(root, "profiles", "hbm_traffic.json")
 d = json.load(open(path))
 src = "blurred-gan_amd/csrc/blur.hip"
 sha = hashlib.sha1(open(os.path.join(root, src), "rb").read()).hexdigest()[:16]

@@ -14,6 +14,7 @@ import sys
 def dispatches(d, counter):
     f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)
     assert f, f"no counter_collection.csv under {d}"
+    assert len(f) == 1, f"{len(f)} counter files under {d}: profile into a fresh directory"
     rows = {}
     for r in csv.DictReader(open(f[0])):
         if r["Counter_Name"] != counter:
