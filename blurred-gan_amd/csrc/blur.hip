@@ -178,6 +178,113 @@ __global__ __launch_bounds__(kMfmaBlurThreads) void blur_mfma_kernel(const float
 }
 
 // ------------------------------------------------------------------------------------------------
+// blur_rows_kernel (round 3): the same two Toeplitz products on images up to 64 x 64 whose rows are float4-addressable
+// (W*C % 4 == 0, C <= 4), with MORE THAN ONE workgroup per CU.  blur_mfma_kernel holds a whole image (two de-interleaved copies,
+// 100 KB of LDS at 64x64x3) in one 16-wave workgroup: 256 images = one workgroup per CU, whose load, H-pass, W-pass and store
+// phases run strictly one after the other (16.3 us for 25 MB, 0.19 of the HBM roof on the headline configuration).  Here a
+// workgroup owns ONE BLOCK OF 32 OUTPUT ROWS of an image and everything stays in the NHWC-interleaved layout:
+//   * it loads the rows within half a kernel of its block -- a contiguous piece of the image -- as straight float4 copies;
+//   * H pass  Y[32][Q] = T_H[32 x rows] * X[rows][Q]  treats a row as Q = W*C independent columns: interleaving is irrelevant;
+//   * W pass per channel  Z[y][x, c] = sum_x' Y[y][x', c] * t[x' - x + half]  reads Y with a stride of C floats along k and writes
+//     Z with a stride of C floats along n -- both conflict-free for odd C (row pitch of Y odd, lanes of a half-wave on 32 banks);
+//   * the 32 result rows leave as straight float4 copies.
+// No de-interleaving index arithmetic, 62 KB of LDS at 64x64x3 / 31 taps -> two 8-wave workgroups per CU, 512 workgroups for 256
+// images: one's loads and stores run under the other's MFMA chains.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRowsThreads = 512;
+constexpr int kRowsBlock = 32;            // output rows per workgroup (one MFMA row block)
+
+struct RowsGeom { int Q, Wp, Qp, pitchY, pitchZ, xfloats, nb; size_t lds; };
+inline RowsGeom rows_geom(int H, int W, int C, int T) {
+  RowsGeom g;
+  const int half = T >> 1;
+  g.Q = W * C;
+  g.Wp = (W + 31) / 32 * 32;
+  g.Qp = (g.Wp * C + 31) / 32 * 32;
+  g.pitchY = g.Qp + 1;                    // odd: the W pass reads Y with lanes along rows
+  g.pitchZ = g.Qp + 4;                    // float4 rows for the copy out
+  g.nb = (H + kRowsBlock - 1) / kRowsBlock;
+  int rows = 0;
+  for (int rb = 0; rb < g.nb; ++rb) rows = std::max(rows, std::min(H, rb * kRowsBlock + kRowsBlock + half) - std::max(0, rb * kRowsBlock - half));
+  rows = (rows + 1) & ~1;
+  g.xfloats = (std::max(rows * g.Qp, kRowsBlock * g.pitchZ) + 3) & ~3;
+  g.lds = ((size_t)g.xfloats + (((size_t)kRowsBlock * g.pitchY + 3) & ~(size_t)3) + T + 2 * kTzPad) * sizeof(float);
+  return g;
+}
+
+__global__ __launch_bounds__(kRowsThreads) void blur_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
+                                                                 int nb, int Qp, int Wp, int xfloats, const float* __restrict__ taps, int T,
+                                                                 FastDiv dQ4) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  constexpr int NTH = kRowsThreads, NW = NTH / 64;
+  const int Q = W * C, q4 = Q >> 2, half = T >> 1;
+  const int pitchY = Qp + 1, pitchZ = Qp + 4;
+  float* X = lds;                                             // [rows][Qp] source rows; later Z [32][pitchZ]
+  float* Y = lds + xfloats;                                   // [32][pitchY] after the H pass
+  float* tz = Y + ((kRowsBlock * pitchY + 3) & ~3);           // [kTzPad zeros][T taps][kTzPad zeros]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int img = blockIdx.x / nb, rb = blockIdx.x - img * nb, r0 = rb * kRowsBlock;
+  const int ks = max(0, r0 - half), ke = min(H, r0 + kRowsBlock + half);       // source rows [ks, ke)
+  const int nk = ke - ks, nk2 = (nk + 1) & ~1;
+  const float* xi = x + (size_t)img * H * Q;
+  float* yi = y + (size_t)img * H * Q;
+  for (int j = tid; j < T + 2 * kTzPad; j += NTH) tz[j] = (j >= kTzPad && j < kTzPad + T) ? taps[j - kTzPad] : 0.f;
+  if (Qp != Q || nk2 != nk) {                                 // columns past the row and the odd k of the last pair must read as zero
+    for (int e = tid; e < nk2 * Qp; e += NTH) X[e] = 0.f;
+    __syncthreads();
+  }
+  {
+    const float4* src = reinterpret_cast<const float4*>(xi + (size_t)ks * Q);
+    const int total4 = nk * q4;
+    for (int i = tid; i < total4; i += NTH) {
+      const int row = fdiv(i, dQ4), c4 = i - row * q4;
+      *reinterpret_cast<float4*>(X + row * Qp + 4 * c4) = src[i];
+    }
+  }
+  __syncthreads();
+  const int li = lane & 31, kk = lane >> 5;
+  // ---- H pass: Y[m][q] = sum_k t[(ks + k) - (r0 + m) + half] * X[k][q];  A = Toeplitz, B = source rows, one 32-column tile per wave
+  for (int item = wave; item < Qp / 32; item += NW) {
+    floatx16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const float* ta = tz + kTzPad + half + ks - r0 - li + kk;       // + k
+    const float* xb = X + kk * Qp + 32 * item + li;                 // + k * Qp
+#pragma unroll 8
+    for (int kp = 0; kp < nk2 / 2; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[2 * kp], xb[2 * kp * Qp], acc, 0, 0, 0);
+    float* yo = Y + (4 * kk) * pitchY + 32 * item + li;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) yo[((q & 3) + 8 * (q >> 2)) * pitchY] = acc[q];
+  }
+  __syncthreads();
+  // ---- W pass per channel: Z[m][x, c] = sum_x' Y[m][x', c] * t[x' - x + half];  A = Y (lanes along rows), B = Toeplitz
+  float* Z = X;                                                     // X is dead: every wave passed the barrier above
+  const int xts = Wp / 32;
+  for (int item = wave; item < C * xts; item += NW) {
+    const int c = item / xts, xt = item - c * xts;
+    floatx16 acc;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
+    const float* ya = Y + li * pitchY + kk * C + c;                 // + k * C
+    const float* tb = tz + kTzPad + half - (32 * xt + li) + kk;     // + k
+#pragma unroll 8
+    for (int kp = 0; kp < Wp / 2; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[2 * kp * C], tb[2 * kp], acc, 0, 0, 0);
+    float* zo = Z + (4 * kk) * pitchZ + (32 * xt + li) * C + c;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) zo[((q & 3) + 8 * (q >> 2)) * pitchZ] = acc[q];
+  }
+  __syncthreads();
+  {
+    float4* dst = reinterpret_cast<float4*>(yi + (size_t)r0 * Q);
+    const int total4 = min(kRowsBlock, H - r0) * q4;
+    for (int i = tid; i < total4; i += NTH) {
+      const int row = fdiv(i, dQ4), c4 = i - row * q4;
+      dst[i] = *reinterpret_cast<const float4*>(Z + row * pitchZ + 4 * c4);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Images larger than 64 x 64: the same Toeplitz product, one direction per launch with a scratch image between them
 // (traffic 2x algorithmic), restricted to the BAND: an output block of 32 rows only contracts over the source rows
 // within half a kernel of it.
@@ -1205,6 +1312,10 @@ static int blur_path(int B, int H, int W, int C, int n_taps) {
   static const int band_t_min = getenv("BG_BLUR_BANDT_MIN_TAPS") ? atoi(getenv("BG_BLUR_BANDT_MIN_TAPS")) : 13;
   const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
   const size_t lds_m = ((size_t)2 * C * Hp * (Wp + 1) + n_taps + 2 * kTzPad) * sizeof(float);
+  const bool no_rows = getenv("BG_BLUR_NO_ROWS") != nullptr;            // test aid, read per call: take the whole-image kernel instead
+  if (!no_rows && H <= 64 && W <= 64 && C <= 4 && ((W * C) & 3) == 0 && n_taps >= mfma_min_taps &&
+      rows_geom(H, W, C, n_taps).lds <= 80 * 1024)
+    return 5;
   if (H <= 64 && W <= 64 && C <= 16 && n_taps >= mfma_min_taps && lds_m <= kFusedLdsCap) return 0;
   const bool fused_fits = fused_lds_bytes(H, W, C) <= kFusedLdsCap && n_taps <= 500;
   const bool band_ok = C <= 4 && (size_t)B * H * W * C < (1ull << 31);
@@ -1219,7 +1330,7 @@ static int blur_path(int B, int H, int W, int C, int n_taps) {
 size_t bg_blur_workspace_bytes(int B, int H, int W, int C, int n_taps) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return 0;
   const int path = blur_path(B, H, W, C, n_taps);
-  return (path <= 1 || path == 4) ? 0 : (size_t)B * H * W * C * sizeof(float);
+  return (path <= 1 || path >= 4) ? 0 : (size_t)B * H * W * C * sizeof(float);
 }
 
 int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const float* taps_d, int n_taps,
@@ -1232,6 +1343,27 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   const double flops = 4.0 * n_taps * (double)total, bytes = 8.0 * (double)total;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int path = blur_path(B, H, W, C, n_taps);
+  auto magic = [](unsigned d) {           // FastDiv: exact for dividends < 2^20
+    FastDiv f;
+    unsigned sft = 0;
+    while ((1u << sft) < d) ++sft;
+    f.sh = 20 + sft;
+    f.mul = (unsigned)(((1ull << f.sh) + d - 1) / d);
+    return f;
+  };
+  if (path == 5) {
+    const RowsGeom g = rows_geom(H, W, C, n_taps);
+    static bool attr_r = false;
+    if (!attr_r) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+      if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "bg_blur_nhwc_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
+      attr_r = true;
+    }
+    bg::Launch L(stream, "blur_rows", flops, bytes);
+    hipLaunchKernelGGL(blur_rows_kernel, dim3((unsigned)(B * g.nb)), dim3(kRowsThreads), g.lds, s, x, y, H, W, C, g.nb, g.Qp, g.Wp, g.xfloats,
+                       taps_d, n_taps, magic((unsigned)(g.Q / 4)));
+    return L.done("blur_rows_kernel");
+  }
   {
     const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
     const size_t lds_m = ((size_t)2 * C * Hp * (Wp + 1) + n_taps + 2 * kTzPad) * sizeof(float);
@@ -1242,14 +1374,6 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
         if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "bg_blur_nhwc_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
         attr_m = true;
       }
-      auto magic = [](unsigned d) {           // exact for dividends < 2^20 (n = H*W*C <= 64*64*16)
-        FastDiv f;
-        unsigned sft = 0;
-        while ((1u << sft) < d) ++sft;
-        f.sh = 20 + sft;
-        f.mul = (unsigned)(((1ull << f.sh) + d - 1) / d);
-        return f;
-      };
       bg::Launch L(stream, "blur_mfma", flops, bytes);
       hipLaunchKernelGGL(blur_mfma_kernel, dim3(B), dim3(kMfmaBlurThreads), lds_m, s, x, y, H, W, C, Hp, Wp, taps_d, n_taps, magic((unsigned)C),
                          magic((unsigned)W));

@@ -40,6 +40,14 @@ struct GatherParams {
   int ksplit;          // split-K factor of the MFMA kernel (1 = none); partial sums go to slab[split][B*Hd*Wd*N]
   float* slab;
   float* stats;        // MFMA kernel: per-workgroup column sums / sums of squares of the stored tile, [row][2][N]; null = off
+  // MFMA kernel, position-major launches: cost-sorted tile order.  Tiles at different output positions run 9 to 16 of their 25
+  // taps, and the hardware places workgroup w of a launch on XCD w % 8 and, within one round of resident workgroups, on the same
+  // CU as w + 256, w + 512, w + 768 (tools/probes/placement.hip).  (phase group, position) pairs are sorted by live taps,
+  // heaviest first, and dealt to the CUs in a snake (even rounds forward, odd rounds backward): every CU's co-resident workgroups
+  // then add up to the same number of K steps, and multi-round grids start their longest workgroups first.
+  int order_n;         // pairs in pp_order (0 = plain (n tile, m tile) x (phase, split) order)
+  int per_pair;        // workgroups per pair = ksplit * N tiles * (B / BM)
+  unsigned char pp_order[256];     // (phase group << 6) | position, by descending cost
   // epilogue
   int epi_mode;
   const float* bias;

@@ -59,15 +59,32 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   // A workgroup owns one output tile of `pm` sub-pixel phases (same anchors, different tap sets and destination offsets).
   // pm = 2 pairs the 9-tap with the 4-tap phase and the two 6-tap phases.
   const int pm = p.pmerge, ngroups = p.nphase / pm;
-  const int pgrp = blockIdx.z % ngroups, split = blockIdx.z / ngroups;
+  int pgrp = blockIdx.z % ngroups, split = blockIdx.z / ngroups;
+  int n_tile, m_tile;
+  const int mt = p.mtiles;
+  if (p.order_n > 0) {
+    // cost-sorted snake (GatherParams::pp_order): 1-D grid, workgroup w sits on CU slot w % 256 in residency round w / 256
+    const int w = blockIdx.x, r = w >> 8;
+    const int u = ((r & 1) && ((r + 1) << 8) <= (int)gridDim.x) ? (r << 8) + 255 - (w & 255) : w;
+    const int pair = u / p.per_pair;
+    int rest = u - pair * p.per_pair;
+    const int code = p.pp_order[pair];
+    const int nt = (p.N + BN - 1) / BN, bch = p.B / BM;
+    pgrp = code >> 6;
+    n_tile = rest % nt;           // N tile fastest: with 8 tiles a weight panel stays on one XCD (w % 8), two panels on odd rounds
+    rest /= nt;
+    split = rest / bch;
+    m_tile = (code & 63) * bch + (rest - split * bch);
+  } else {
+    // logical tile list is n-major (all M tiles of one weight panel, then the next panel): with the XCD remap each
+    // XCD's L2 holds only its share of the weight panels while the activations stream through
+    const int L = p.xcd_swizzle ? bg::xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    n_tile = L / mt;
+    m_tile = L - n_tile * mt;
+  }
   auto phase_of = [&](int q) { return pm == 2 ? (q == 0 ? pgrp : p.nphase - 1 - pgrp) : pgrp * pm + q; };
   const GatherPhase& g = p.ph[phase_of(0)];
   const int Mph = p.B * g.Ha * g.Wa;
-  // logical tile list is n-major (all M tiles of one weight panel, then the next panel): with the XCD remap each
-  // XCD's L2 holds only its share of the weight panels while the activations stream through
-  const int mt = p.mtiles;
-  const int L = p.xcd_swizzle ? bg::xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
-  const int n_tile = L / mt, m_tile = L - n_tile * mt;
   const int m0 = m_tile * BM;
   const int n0 = n_tile * BN;
   const int tid = threadIdx.x;
@@ -864,6 +881,40 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
     }
   }
   dim3 grid(p.mtiles * bg::cdiv(p.N, BN), 1, (p.nphase / p.pmerge) * ks);
+  p.order_n = 0;
+  static const int no_sort = getenv("BG_NO_TILE_SORT") ? 1 : 0;
+  bool uniform = true;          // every phase has the same anchor grid (else the sorted order leaves some (group, M tile) rows of the
+  for (int i = 1; i < p.nphase; ++i) uniform = uniform && p.ph[i].Ha * p.ph[i].Wa == p.ph[0].Ha * p.ph[0].Wa;   // statistics partials unwritten)
+  if (p.pos_major && !no_sort && (uniform || !(epi && epi->stats))) {
+    // cost of a (phase group, position) pair = live taps of the group's phases there (the K steps its workgroups run)
+    struct PP { int cost, code; };
+    PP v[256];
+    int n = 0;
+    const int pm = p.pmerge, ngroups = p.nphase / pm;
+    bool fits = true;
+    for (int g = 0; g < ngroups && fits; ++g) {
+      auto phase_of = [&](int q) { return pm == 2 ? (q == 0 ? g : p.nphase - 1 - g) : g * pm + q; };
+      const GatherPhase& g0 = p.ph[phase_of(0)];
+      for (int pos = 0; pos < g0.Ha * g0.Wa; ++pos) {
+        int live = 0;
+        for (int q = 0; q < pm; ++q) {
+          const GatherPhase& gq = p.ph[phase_of(q)];
+          const int sy = (pos / g0.Wa) * p.ss, sx = (pos % g0.Wa) * p.ss;
+          for (int t = 0; t < gq.ntaps; ++t)
+            live += ((unsigned)(sy + bg::tap_dy(gq.tap[t])) < (unsigned)p.Hs && (unsigned)(sx + bg::tap_dx(gq.tap[t])) < (unsigned)p.Ws) ? 1 : 0;
+        }
+        if (n == 256 || pos >= 64 || g >= 4) { fits = false; break; }
+        v[n++] = PP{live, (g << 6) | pos};
+      }
+    }
+    if (fits && n > 0) {
+      std::stable_sort(v, v + n, [](const PP& a, const PP& b) { return a.cost > b.cost; });
+      for (int i = 0; i < n; ++i) p.pp_order[i] = (unsigned char)v[i].code;
+      p.order_n = n;
+      p.per_pair = ks * (int)bg::cdiv(p.N, BN) * (p.B / BM);
+      grid = dim3((unsigned)(n * p.per_pair), 1, 1);
+    }
+  }
   {
     // BatchNorm statistics in the epilogue: plain stores only (no split-K slabs, no bias / activation), one row per workgroup
     const size_t srows = (size_t)(p.nphase / p.pmerge) * p.mtiles;

@@ -58,6 +58,23 @@ def test_band_passes_slower_loaders(shape, std, ld, monkeypatch):
     np.testing.assert_allclose(y, O.blur_images(x.astype(np.float64), std), rtol=POINT_RTOL, atol=POINT_ATOL * 4)
 
 
+@pytest.mark.parametrize("shape,std", [((5, 64, 64, 3), 5.0), ((3, 64, 64, 3), 10.5), ((2, 64, 64, 1), 5.0), ((3, 28, 28, 1), 9.0),
+                                       ((2, 48, 40, 3), 3.0), ((3, 33, 64, 3), 2.0), ((2, 64, 36, 1), 4.0), ((2, 40, 24, 2), 3.0),
+                                       ((2, 60, 32, 4), 2.5), ((1, 17, 4, 1), 2.0)])
+def test_small_image_kernels_row_blocks_and_whole_image(shape, std, monkeypatch):
+    """Images up to 64 x 64 at >= 13 taps: the row-block kernel (blur_rows_kernel: 32 output rows per workgroup, NHWC-interleaved
+    Toeplitz products; float4-addressable rows, <= 4 channels) and, forced, the whole-image kernel it replaced -- one and two
+    row blocks, partial last block, rows narrower than a column tile, every channel count."""
+    x = np.random.default_rng(11).uniform(-1, 1, size=shape).astype(np.float32)
+    ref = O.blur_images(x.astype(np.float64), std)
+    assert O.blur_policy(std, shape[1], shape[2])[2] >= 13
+    y, _ = _run(x, std)
+    np.testing.assert_allclose(y, ref, rtol=POINT_RTOL, atol=POINT_ATOL * 4)
+    monkeypatch.setenv("BG_BLUR_NO_ROWS", "1")
+    y0, _ = _run(x, std)
+    np.testing.assert_allclose(y0, ref, rtol=POINT_RTOL, atol=POINT_ATOL * 4)
+
+
 def _random_blur_cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []

@@ -196,10 +196,10 @@ def test_local_rank_beyond_visible_devices_is_an_error(monkeypatch):
     monkeypatch.setenv("LOCAL_RANK", str(n))
     monkeypatch.delenv("BGAN_DIST_SHARE_DEVICES", raising=False)
     monkeypatch.delenv("BGAN_DIST_BACKEND", raising=False)
+    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):       # the box itself may mask its one card
+        monkeypatch.delenv(v, raising=False)
     with pytest.raises(RuntimeError, match="LOCAL_RANK"):
         dist.local_rank()
-    for v in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
-        monkeypatch.delenv(v, raising=False)
     monkeypatch.setenv("BGAN_DIST_SHARE_DEVICES", "1")           # sharing a card under RCCL hangs: the switch alone is refused
     with pytest.raises(RuntimeError, match="LOCAL_RANK"):
         dist.local_rank()
