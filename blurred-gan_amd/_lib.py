@@ -34,6 +34,9 @@ SIGNATURES = {
     "bg_prof_count": (_i, []),
     "bg_prof_get": (_i, [_i, C.c_char_p, _i, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bg_prof_get_exec": (_i, [_i, C.POINTER(C.c_double)]),
+    "bg_range_enable": (_i, [_i]),
+    "bg_range_push": (_i, [C.c_char_p]),
+    "bg_range_pop": (_i, []),
     "bg_blur_policy": (_i, [_f, _i, _i, C.POINTER(_f), C.POINTER(_f), C.POINTER(_i)]),
     "bg_gauss_kernel_1d": (_i, [_f, _f, C.POINTER(_f), _i, C.POINTER(_i)]),
     "bg_blur_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),

@@ -45,6 +45,8 @@ struct GatherParams {
   // CU as w + 256, w + 512, w + 768 (tools/probes/placement.hip).  (phase group, position) pairs are sorted by live taps,
   // heaviest first, and dealt to the CUs in a snake (even rounds forward, odd rounds backward): every CU's co-resident workgroups
   // then add up to the same number of K steps, and multi-round grids start their longest workgroups first.
+  unsigned char grp_order[4];      // plain order: phase groups by descending tap count (grid.z walks them heaviest first, so a multi-round
+                                   // grid ends on its SHORT workgroups: the 4-tap phase of a stride-2 transposed conv, not the 9-tap one)
   int order_n;         // pairs in pp_order (0 = plain (n tile, m tile) x (phase, split) order)
   int per_pair;        // workgroups per pair = ksplit * N tiles * (B / BM)
   unsigned char pp_order[256];     // (phase group << 6) | position, by descending cost

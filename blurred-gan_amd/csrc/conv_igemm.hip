@@ -59,7 +59,7 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   // A workgroup owns one output tile of `pm` sub-pixel phases (same anchors, different tap sets and destination offsets).
   // pm = 2 pairs the 9-tap with the 4-tap phase and the two 6-tap phases.
   const int pm = p.pmerge, ngroups = p.nphase / pm;
-  int pgrp = blockIdx.z % ngroups, split = blockIdx.z / ngroups;
+  int pgrp = p.grp_order[blockIdx.z % ngroups], split = blockIdx.z / ngroups;
   int n_tile, m_tile;
   const int mt = p.mtiles;
   if (p.order_n > 0) {
@@ -883,6 +883,14 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
   dim3 grid(p.mtiles * bg::cdiv(p.N, BN), 1, (p.nphase / p.pmerge) * ks);
   p.order_n = 0;
   static const int no_sort = getenv("BG_NO_TILE_SORT") ? 1 : 0;
+  {
+    const int pm = p.pmerge, ngroups = p.nphase / pm;
+    int cost[4] = {0, 0, 0, 0}, idx[4] = {0, 1, 2, 3};
+    for (int g = 0; g < ngroups; ++g)
+      for (int q = 0; q < pm; ++q) cost[g] += p.ph[pm == 2 ? (q == 0 ? g : p.nphase - 1 - g) : g * pm + q].ntaps;
+    if (!no_sort) std::stable_sort(idx, idx + ngroups, [&](int a, int b) { return cost[a] > cost[b]; });
+    for (int g = 0; g < 4; ++g) p.grp_order[g] = (unsigned char)idx[g];
+  }
   bool uniform = true;          // every phase has the same anchor grid (else the sorted order leaves some (group, M tile) rows of the
   for (int i = 1; i < p.nphase; ++i) uniform = uniform && p.ph[i].Ha * p.ph[i].Wa == p.ph[0].Ha * p.ph[0].Wa;   // statistics partials unwritten)
   if (p.pos_major && !no_sort && (uniform || !(epi && epi->stats))) {

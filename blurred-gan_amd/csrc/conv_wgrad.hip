@@ -30,6 +30,10 @@ struct WgradParams {
   unsigned x_bytes, dy_bytes;
   unsigned mul_hw, sh_hw, mul_w, sh_w;   // magic-number division by Ho*Wo and Wo (dividends < 2^31)
   int lg_w, lg_h, lg_b, pow2;            // log2(Wo), log2(Ho), log2(B); pow2 = 1: Ho, Wo powers of two; 2: + B, small map (position-major)
+  // position-major launches of the per-tap kernel: taps sorted by their live output positions (a corner tap of a 4x4 map sees 4
+  // of the 16 positions, the centre tap all 16), heaviest first, and dealt to the CUs in a snake -- see GatherParams::pp_order
+  int order_n;                           // 0 = plain (tile, tap, split) order; else k*k
+  unsigned char tap_order[32];
 };
 
 // floor(m / d) for m < 2^31 with host-computed (mul, sh): q = (m * mul) >> sh
@@ -62,9 +66,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
   const int wm = wmn / WAVES_N, wn = wmn % WAVES_N;
   // 1-D grid, logical order (tile, tap, split) with the pixel split slowest; the XCD remap gives every XCD whole
   // splits, so the workgroups that re-read the same x / dy chunk (all taps and channel tiles of a split) share an L2
-  const int L = p.xcd_swizzle ? bg::xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   const int ntile = p.tiles_m * p.tiles_n, ntap = p.k * p.k;
-  const int tile = L % ntile, tap = (L / ntile) % ntap, zsplit = L / (ntile * ntap);
+  int tile, tap, zsplit;
+  if (P2 == 2 && p.order_n > 0) {
+    // workgroup w sits on CU slot w % 256 in residency round w / 256 (tools/probes/placement.hip): cost-sorted snake
+    const int w = blockIdx.x, r = w >> 8;
+    const int u = ((r & 1) && ((r + 1) << 8) <= (int)gridDim.x) ? (r << 8) + 255 - (w & 255) : w;
+    tile = u % ntile;
+    const int rest = u / ntile;
+    zsplit = rest % p.ksplit;
+    tap = p.tap_order[rest / p.ksplit];
+  } else {
+    const int L = p.xcd_swizzle ? bg::xcd_remap(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+    tile = L % ntile; tap = (L / ntile) % ntap; zsplit = L / (ntile * ntap);
+  }
   const int tile_m = tile / p.tiles_n, tile_n = tile % p.tiles_n;
   const int ci0 = tile_m * BM, co0 = tile_n * BN;
   const int kh = tap / p.k, kw = tap % p.k;
@@ -1381,6 +1396,23 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     p.xcd_swizzle = (pl.mode == 6 || pl.mode == 7) ? swz_tg : swz;
   }
   p.beta = beta; p.scale = scale;
+  p.order_n = 0;
+  {
+    static const int no_sort = getenv("BG_NO_TILE_SORT") ? 1 : 0;
+    if (p.pow2 == 2 && pl.taps_in_grid == 1 && pl.mode >= 1 && pl.mode <= 5 && !no_sort && ksize * ksize <= 32) {
+      int live[32], idx[32];
+      for (int t = 0; t < ksize * ksize; ++t) {
+        const int dyk = t / ksize - p.pt, dxk = t % ksize - p.pl;
+        const int oh_lo = std::max(0, (-dyk + stride - 1) / stride), oh_hi = std::min(p.Ho - 1, (H - 1 - dyk) / stride);
+        const int ow_lo = std::max(0, (-dxk + stride - 1) / stride), ow_hi = std::min(p.Wo - 1, (W - 1 - dxk) / stride);
+        live[t] = std::max(0, oh_hi - oh_lo + 1) * std::max(0, ow_hi - ow_lo + 1);
+        idx[t] = t;
+      }
+      std::stable_sort(idx, idx + ksize * ksize, [&](int a, int b) { return live[a] > live[b]; });
+      for (int t = 0; t < ksize * ksize; ++t) p.tap_order[t] = (unsigned char)idx[t];
+      p.order_n = ksize * ksize;
+    }
+  }
   p.out = pl.ksplit > 1 ? static_cast<float*>(ws_d) : dw;
   const double flops = 2.0 * p.M * (double)nout;
   int rc;

@@ -1,5 +1,6 @@
 // Meta entry points, thread-local error message, per-launch HIP-event profiling (bench.py roofline).
 #include "common.h"
+#include <dlfcn.h>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -106,6 +107,42 @@ int bg_prof_get(int i, char* name, int name_cap, float* ms, double* flops, doubl
   if (ms) *ms = t;
   if (flops) *flops = r.flops;
   if (bytes) *bytes = r.bytes;
+  return BG_OK;
+}
+
+// ---- roctx ranges (rocprofv3 --marker-trace); the library is looked up at run time, never linked
+namespace {
+typedef int (*roctx_push_t)(const char*);
+typedef int (*roctx_pop_t)(void);
+roctx_push_t g_rpush = nullptr;
+roctx_pop_t g_rpop = nullptr;
+int g_range_on = 0;
+}  // namespace
+
+int bg_range_enable(int on) {
+  g_range_on = 0;
+  if (!on) return 0;
+  if (!g_rpush) {
+    for (const char* name : {"librocprofiler-sdk-roctx.so", "librocprofiler-sdk-roctx.so.1", "libroctx64.so", "libroctx64.so.4"}) {
+      void* h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (!h) continue;
+      g_rpush = reinterpret_cast<roctx_push_t>(dlsym(h, "roctxRangePushA"));
+      g_rpop = reinterpret_cast<roctx_pop_t>(dlsym(h, "roctxRangePop"));
+      if (g_rpush && g_rpop) break;
+      g_rpush = nullptr; g_rpop = nullptr;
+    }
+  }
+  g_range_on = (g_rpush && g_rpop) ? 1 : 0;
+  return g_range_on;
+}
+
+int bg_range_push(const char* name) {
+  if (g_range_on && name) (void)g_rpush(name);
+  return BG_OK;
+}
+
+int bg_range_pop(void) {
+  if (g_range_on) (void)g_rpop();
   return BG_OK;
 }
 

@@ -183,6 +183,12 @@ class GradReducer:
             return
         seg = self.flat[lo:hi]
         self.n_collectives += 1
+        from . import ops
+        with ops.trace_range("all_reduce"):
+            self._issue_seg(seg)
+        self.covered.append((lo, hi))
+
+    def _issue_seg(self, seg):
         if _use_abi_comm(seg):
             self.works.append(AbiComm.get().all_reduce_async(seg))
         elif seg.is_cuda and td.get_backend() == "gloo":        # CPU-side rehearsal: stage through the host, synchronous
@@ -191,7 +197,6 @@ class GradReducer:
             seg.copy_(host)
         else:
             self.works.append(td.all_reduce(seg, op=td.ReduceOp.SUM, async_op=True))
-        self.covered.append((lo, hi))
 
     def ready(self, lo, hi):
         """Elements [lo, hi) of the buffer are final (their last kernel has been enqueued on the current stream).

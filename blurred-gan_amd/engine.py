@@ -238,7 +238,8 @@ class Net:
         taps, nt = self.blur_taps(H, W)
         nb = ops.blur_workspace_bytes(B, H, W, C, nt)
         tmp = self.workspace(nb) if nb else None
-        return ops.blur_nhwc(x, y, taps, nt, tmp)
+        with ops.trace_range("blur"):
+            return ops.blur_nhwc(x, y, taps, nt, tmp)
 
     # ------------------------------------------------------------------ forward
     def forward(self, ctx: Context, inputs, training=False, masks=None, seed=0):

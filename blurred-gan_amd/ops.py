@@ -362,6 +362,32 @@ def keep_mask(out, keep_prob, seed, offset=0):
 
 
 # ------------------------------------------------------------------ profiling
+_ranges_on = None
+
+
+class trace_range:
+    """Named range on the rocprofv3 marker timeline (roctx through the C ABI).  Off unless BGAN_ROCTX=1: then the first use binds
+    roctx; with the switch off (the default) entering and leaving cost one attribute test."""
+    __slots__ = ("name",)
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        global _ranges_on
+        if _ranges_on is None:
+            import os
+            _ranges_on = bool(os.environ.get("BGAN_ROCTX") == "1" and _lib.load().bg_range_enable(1))
+        if _ranges_on:
+            _lib.load().bg_range_push(self.name.encode())
+        return self
+
+    def __exit__(self, *exc):
+        if _ranges_on:
+            _lib.load().bg_range_pop()
+        return False
+
+
 def prof_enable(on):
     _lib.load().bg_prof_enable(int(on))
 

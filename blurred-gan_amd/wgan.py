@@ -207,10 +207,12 @@ class WGAN:
         self._injected = randomness
         self._defer_metrics = True
         try:
-            disc_loss, self.images = self.discriminator_step(reals)
+            with ops.trace_range("d_step"):
+                disc_loss, self.images = self.discriminator_step(reals)
             g_ran = int(self.n_batches) % self.d_steps_per_g_step == 0
             if g_ran:
-                self.generator_step()
+                with ops.trace_range("g_step"):
+                    self.generator_step()
         finally:
             self._injected = None
             self._defer_metrics = False

@@ -54,6 +54,13 @@ int bg_prof_get(int i, char* name, int name_cap, float* ms, double* flops, doubl
    position-major tiles skip.  Equals the algorithmic figure of bg_prof_get for kernels that do not report their own. */
 int bg_prof_get_exec(int i, double* exec_flops);
 
+/* Named ranges on the profiler timeline (rocprofv3 --marker-trace): D-step / G-step / blur / all-reduce of one train_on_batch
+   (wgan.py:86-114).  roctx (librocprofiler-sdk-roctx.so) is bound with dlopen on first use; without it, or with
+   bg_range_enable(0) (the default), both calls return immediately.  bg_range_enable returns 1 when ranges will be emitted. */
+int bg_range_enable(int on);
+int bg_range_push(const char* name);
+int bg_range_pop(void);
+
 /* ---- Gaussian blur: gaussian_blur.py:15-132 ---------------------------------------------- */
 /* gaussian_blur.py:21-31,58-72 (appropriate_kernel_size, appropriate_std, clip, max): host maths, float32. */
 int bg_blur_policy(float sigma, int H, int W, float* kernel_size, float* sigma_eff, int* n_taps);

@@ -130,11 +130,15 @@ TRAINABLE = ("kernel", "bias", "gamma", "beta")
 # ----------------------------------------------------------------------------
 # interpreter
 # ----------------------------------------------------------------------------
-def forward(spec, params, x, training, masks=None, update_bn=None):
+def forward(spec, params, x, training, masks=None, update_bn=None, lrelu_masks=None):
     """Runs the stack.  ``masks``: list of keep-masks, one per dropout layer, used when training.
     ``update_bn``: dict collecting new moving stats (layer index -> (mean, var)) when training.
+    ``lrelu_masks`` (test aid): one array of LeakyReLU derivatives (1 / alpha) per LeakyReLU layer, used INSTEAD of the signs this
+    pass computes -- the gradient of the network is discontinuous where a pre-activation crosses zero, and a float32
+    implementation within 1e-7 of the kink may sit on the other branch; with the branches of the implementation under test
+    forced, the comparison is between the same piecewise-linear function.  Forward VALUES still follow this pass's own signs.
     Returns (out, cache)."""
-    cache, mi = [], 0
+    cache, mi, li = [], 0, 0
     for i, (L, p) in enumerate(zip(spec, params)):
         t = L["type"]
         c = {"x": x}
@@ -163,7 +167,8 @@ def forward(spec, params, x, training, masks=None, update_bn=None):
             else:
                 x = O.bn_infer_fwd(x, p["gamma"], p["beta"], p["moving_mean"], p["moving_var"])
         elif t == "lrelu":
-            c["m"] = O.lrelu_mask(x)
+            c["m"] = O.lrelu_mask(x) if lrelu_masks is None else np.asarray(lrelu_masks[li], dtype=x.dtype).reshape(x.shape)
+            li += 1
             x = O.lrelu_fwd(x)
         elif t == "dropout":
             if training:

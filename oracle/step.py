@@ -49,19 +49,19 @@ def draw_randomness(arch, batch, rng, dtype=np.float32):
                 mask_fake=mk(), mask_real=mk())
 
 
-def critic_fwd(st, x, training, masks=None):
+def critic_fwd(st, x, training, masks=None, lrelu_masks=None):
     """D~ = Sequential([GaussianBlur2D, D]) (blurred_gan.py:30-34)."""
     a0 = O.blur_images(x, st["std"])
-    y, cache = M.forward(st["dspec"], st["d"], a0, training, masks)
+    y, cache = M.forward(st["dspec"], st["d"], a0, training, masks, lrelu_masks=lrelu_masks)
     return y, cache
 
 
-def gradient_penalty(st, reals, fakes, alpha, want_grads=True):
+def gradient_penalty(st, reals, fakes, alpha, want_grads=True, lrelu_masks=None):
     """wgan.py:234-246 + its gradient w.r.t. critic weights (second order)."""
     B = reals.shape[0]
     a = alpha.reshape(B, 1, 1, 1).astype(reals.dtype)
     xhat = reals + a * (fakes - reals)
-    yhat, cache = critic_fwd(st, xhat, training=False)
+    yhat, cache = critic_fwd(st, xhat, training=False, lrelu_masks=lrelu_masks)
     dz = {}
     _, d0 = M.backward(st["dspec"], st["d"], cache, np.ones_like(yhat), need_dx=True, need_dw=False,
                        training=False, keep_dz=dz)
@@ -84,8 +84,10 @@ def _acc(dst, src, scale=1.0):
     return dst
 
 
-def discriminator_grads(st, reals, rnd, hp):
-    """wgan.py:132-151 + 272-285.  Returns (grads, metrics, fakes)."""
+def discriminator_grads(st, reals, rnd, hp, force=None):
+    """wgan.py:132-151 + 272-285.  Returns (grads, metrics, fakes).  ``force`` (test aid, see models.forward): LeakyReLU
+    branches per critic pass, {"fake": [...], "real": [...], "hat": [...]}."""
+    force = force or {}
     B = reals.shape[0]
     dt = reals.dtype.type
     inv_gbs = dt(1.0 / hp["global_batch_size"])
@@ -93,10 +95,10 @@ def discriminator_grads(st, reals, rnd, hp):
     # B * dp_world samples; its gradients are meant to be SUMMED over the shards.
     Bg = B * int(hp.get("dp_world", 1))
     fakes, _ = M.forward(st["gspec"], st["g"], rnd["z_d"], training=False)           # Q4
-    fs, cf = critic_fwd(st, fakes, True, rnd["mask_fake"])
-    rs, cr = critic_fwd(st, reals, True, rnd["mask_real"])
+    fs, cf = critic_fwd(st, fakes, True, rnd["mask_fake"], force.get("fake"))
+    rs, cr = critic_fwd(st, reals, True, rnd["mask_real"], force.get("real"))
     l_w = (fs - rs).sum() * inv_gbs
-    gp, gp_grads, _ = gradient_penalty(st, reals, fakes, rnd["alpha"])
+    gp, gp_grads, _ = gradient_penalty(st, reals, fakes, rnd["alpha"], lrelu_masks=force.get("hat"))
     gp_term = dt(hp["gp_coefficient"]) * gp
     norm_term = dt(hp["e_drift"]) * (np.abs(fs[:, 0]) + np.abs(rs[:, 0]))             # [B]
     disc_loss_vec = l_w + gp_term + norm_term                                           # Q1: [B]
@@ -116,13 +118,14 @@ def discriminator_grads(st, reals, rnd, hp):
     return grads, metrics, fakes
 
 
-def generator_grads(st, rnd, hp, batch):
-    """wgan.py:159-172."""
+def generator_grads(st, rnd, hp, batch, force=None):
+    """wgan.py:159-172.  ``force`` (test aid): LeakyReLU branches, {"g": [...] generator, "d_gstep": [...] critic}."""
+    force = force or {}
     upd = {}
-    fakes, cg = M.forward(st["gspec"], st["g"], rnd["z_g"], training=True, update_bn=upd)
+    fakes, cg = M.forward(st["gspec"], st["g"], rnd["z_g"], training=True, update_bn=upd, lrelu_masks=force.get("g"))
     ks, s, _ = O.blur_policy(st["std"], fakes.shape[1], fakes.shape[2])
     a0 = O.gaussian_blur(fakes, s, ks)
-    sc, cd = M.forward(st["dspec"], st["d"], a0, training=False)
+    sc, cd = M.forward(st["dspec"], st["d"], a0, training=False, lrelu_masks=force.get("d_gstep"))
     inv_gbs = fakes.dtype.type(1.0 / hp["global_batch_size"])
     gen_loss = -sc.sum() * inv_gbs
     dsc = np.full_like(sc, -inv_gbs)
@@ -138,16 +141,17 @@ def _adam(params, ms, vs, grads, t, lr):
             p[k], m[k], v[k] = O.adam_update(p[k], m[k], v[k], g[k].astype(p[k].dtype), t, lr)
 
 
-def train_on_batch(st, reals, rnd, hp=None):
-    """wgan.py:86-114.  Mutates and returns ``st``; also returns the metrics dict and aux grads."""
+def train_on_batch(st, reals, rnd, hp=None, force=None):
+    """wgan.py:86-114.  Mutates and returns ``st``; also returns the metrics dict and aux grads.  ``force``: see
+    discriminator_grads / generator_grads (test aid)."""
     hp = dict(DEFAULT_HP, **(hp or {}))
     B = reals.shape[0]
-    dg, met, fakes = discriminator_grads(st, reals, rnd, hp)
+    dg, met, fakes = discriminator_grads(st, reals, rnd, hp, force)
     st["d_t"] += 1
     _adam(st["d"], st["d_m"], st["d_v"], dg, st["d_t"], hp["learning_rate"])
     aux = dict(d_grads=dg, fakes=fakes)
     if st["n_batches"] % hp["d_steps_per_g_step"] == 0:
-        gg, upd, gm = generator_grads(st, rnd, hp, B)
+        gg, upd, gm = generator_grads(st, rnd, hp, B, force)
         st["g_t"] += 1
         _adam(st["g"], st["g_m"], st["g_v"], gg, st["g_t"], hp["learning_rate"])
         for i, (nm, nv) in upd.items():

@@ -140,3 +140,22 @@ def check_grad_quality(prod, ora, key, label, ora32=None, l2_bound=None, cos_bou
     print(f"[grad quality] {label}: rel-L2 / (1-cos) per variable: {line}")
     assert not bad, f"{label}: variables {bad} exceed max(rel-L2 {l2_bound:g}, 1-cos {cos_bound:g}; {YARDSTICK:g} x float32 oracle): {line}"
     return table
+
+
+def product_lrelu_branches(gan, B):
+    """LeakyReLU branch decisions (1 / alpha per unit) the product took in its LAST train_on_batch, read back from the
+    activations its passes left in their contexts (merged critic pass "fr3": rows [0, B) fakes, [B, 2B) reals, [2B, 3B) x-hat;
+    G-step: generator "g", critic "hat").  Shaped for oracle.step's ``force`` argument.  A unit that Dropout zeroed reads as
+    alpha here and is multiplied by its keep mask (0) in the oracle's backward anyway."""
+    G, D = gan.generator.net(), gan.discriminator.net()
+
+    def masks(net, ctx, lo=None, hi=None):
+        out = []
+        for i, st in enumerate(net.stages):
+            if st.act == "lrelu":
+                a = ctx.a[i] if lo is None else ctx.a[i][lo:hi]
+                out.append(np.where(a.detach().cpu().numpy() > 0, 1.0, float(st.alpha)))
+        return out
+    c3 = D.context(3 * B, "fr3", drop_rows=2 * B)
+    return {"fake": masks(D, c3, 0, B), "real": masks(D, c3, B, 2 * B), "hat": masks(D, c3, 2 * B, 3 * B),
+            "g": masks(G, G.context(B, "g")), "d_gstep": masks(D, D.context(B, "hat"))}

@@ -36,19 +36,19 @@ def _build(arch, B, gbs, seed=3):
     gan = bg.BlurredWGANGP(gen, disc, hp, bg.TrainingConfig(log_dir="/tmp/bg_dp_logs"))
     load_oracle_weights(gen, st["g"])
     load_oracle_weights(disc, st["d"])
-    reals = rng.uniform(-1, 1, size=(gbs, 8, 8, 3)).astype(np.float32)
+    reals = rng.uniform(-1, 1, size=(gbs,) + tuple(models.IMAGE_SHAPE[arch])).astype(np.float32)
     rnd = S.draw_randomness(arch, gbs, rng, np.float64)
     return gan, reals, rnd
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, arch="tiny", B_local=3):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     import sys
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     from blurred_gan_amd import dist
     torch.cuda.set_device(0)
     torch.distributed.init_process_group(backend="gloo")
-    gan, reals, rnd = _build("tiny", 3, 6)
+    gan, reals, rnd = _build(arch, B_local, B_local * world)
     sh = lambda a: dist.shard(torch.from_numpy(np.asarray(a))).numpy()
     rnd_local = {k: ([sh(m) for m in v] if isinstance(v, list) else sh(v)) for k, v in rnd.items()}
     gan.train_on_batch(sh(reals), randomness=rnd_local)
@@ -63,10 +63,11 @@ def _worker(rank, world, port, out_dir):
     torch.distributed.destroy_process_group()
 
 
-def test_two_ranks_match_single_process_global_batch(tmp_path):
+@pytest.mark.parametrize("arch,B_local", [("tiny", 3), ("mnist", 4)])          # the 8x8 test stack and the real MNIST stack at global batch 8
+def test_two_ranks_match_single_process_global_batch(tmp_path, arch, B_local):
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    gan, reals, rnd = _build("tiny", 6, 6)
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), arch, B_local), nprocs=world, join=True)
+    gan, reals, rnd = _build(arch, B_local * world, B_local * world)
     gan.train_on_batch(reals, randomness=rnd)
     st = gan.discriminator.store
     ref_g, ref_t = st.grad[:st.n_train].cpu().numpy(), st.theta[:st.n_train].cpu().numpy()
@@ -213,3 +214,21 @@ def test_local_rank_beyond_visible_devices_is_an_error(monkeypatch):
         monkeypatch.delenv("ROCR_VISIBLE_DEVICES")
     monkeypatch.setenv("LOCAL_RANK", "0")
     assert dist.local_rank() == 0
+
+
+def test_bench_two_ranks_strong_scaling_smoke():
+    """bench.py --gpus 2 --strong (the launcher path of the contract: bench.py starts torch.distributed.run itself), two ranks
+    sharing the box's one card over gloo (the rehearsal mode): ONE JSON line, n_gpus 2, strong scaling, the global batch split."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BGAN_DIST_BACKEND="gloo", BGAN_DIST_SHARE_DEVICES="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--strong", "--arch", "mnist", "--batch", "16",
+                        "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-profile"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_batch"] == 16 and out["value"] > 0
+    assert out["config"]["parallelism"] == "dp2" and "8/GPU" in out["config"]["workload"]
