@@ -386,6 +386,7 @@ class Net:
         g, g_is_dz = dout, False
         sync_bn = self.sync_bn and dist.collectives_active()
         pending_stats = None        # SyncBN: the all-reduce of the NEXT (lower) stage's backward statistics, in flight
+        deferred_ready = []         # SyncBN overlap: gradient slices finished but not yet handed to the reducer (see weight_grads)
         for i in range(len(self.stages) - 1, -1, -1):
             st = self.stages[i]
             gv = g.view(B, *st.out_shape)
@@ -435,7 +436,7 @@ class Net:
             lin = st.lin
             prev = self.stages[i - 1] if i > 0 else None
 
-            def weight_grads():
+            def weight_grads(defer_ready=False):
                 dW = st_.grad_of(lin, "kernel")
                 xw, dzw = (xin, dz) if WB == B else (xin[:WB], dz.view(B, *st.out_shape)[:WB])
                 if st.kind == "dense":
@@ -457,7 +458,13 @@ class Net:
                     ws = self.workspace(ops.colsum_workspace_bytes(rows, N))
                     ops.colsum(dzw, st_.grad_of(lin, "bias"), rows, N, ws, beta=beta, scale=scale)
                 if reducer is not None:
-                    reducer.ready(*st_.train_range(lin, st.bn))
+                    # Under the SyncBN overlap a slice is NOT handed over right away: ready() may flush a 16 MB bucket onto the
+                    # collective stream, and the small statistics exchange of the next stage down, issued one iteration later,
+                    # would queue behind it -- back on the critical path.  The slice waits until that exchange is in flight.
+                    if defer_ready:
+                        deferred_ready.append(st_.train_range(lin, st.bn))
+                    else:
+                        reducer.ready(*st_.train_range(lin, st.bn))
 
             # SyncBN with a BatchNorm stage below: the data gradient goes FIRST, the lower stage's backward statistics are
             # reduced and their all-reduce is put in flight, and only then this stage's filter gradient runs -- the small
@@ -469,6 +476,9 @@ class Net:
                 weight_grads()
             # ---- input gradient
             if i == 0 and not need_dx:
+                if reducer is not None:
+                    for rng in deferred_ready:
+                        reducer.ready(*rng)
                 return None
             fuse = prev is not None and prev.fusable_grad and st.kind != "dense"
             tgt = ctx.buf(ctx.dz, i - 1).view(B, *st.in_shape) if i > 0 else ctx.input_grad().view(B, *st.in_shape)
@@ -507,8 +517,15 @@ class Net:
                 ops.bn_bwd_stats(gp, ctx.a[i - 1], ctx.z[i - 1], Mp, Cp, ctx.mean[i - 1], ctx.inv[i - 1], sums,
                                  self.workspace(ops._lib.load().bg_bn_workspace_bytes(Mp, Cp)), lrelu_alpha=prev.alpha)
                 pending_stats = dist.all_reduce_sum_async(sums)
-                weight_grads()
+                if reducer is not None:             # slices finished before this exchange was issued may go out behind it now
+                    for rng in deferred_ready:
+                        reducer.ready(*rng)
+                    deferred_ready.clear()
+                weight_grads(defer_ready=True)
             g, g_is_dz = tgt, fuse
+        if reducer is not None:
+            for rng in deferred_ready:
+                reducer.ready(*rng)
         din = g
         if self.blur is not None:
             # forward's blurred input is dead by now; reuse it for blur^T(din)

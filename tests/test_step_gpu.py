@@ -106,11 +106,14 @@ def test_real_architecture_training_steps_match_oracle(arch, B, std, steps):
     exercises the flat-buffer Adam (bias correction at t = 1, 2, 3), the refresh of the transposed weight copies the forward
     kernels read, and the G-step's moving-statistics update at 16 M parameters.
 
-    Why the oracle is re-synchronised to the product's state before each step: a free-running comparison is ill-conditioned,
-    not informative.  Adam's first updates are lr * g / (|g| + 1e-7), so a weight whose gradient is within float32 noise of
-    zero steps +lr in one implementation and -lr in the other, and BatchNorm at a small batch amplifies that: the ORACLE
-    ITSELF run in float32 is 7e-2 (step 2) and 0.27 (step 3) of the maximum away from its float64 run on the generator's first
-    moments at celeba64 / batch 8.  Compared step by step from a common state the slots agree to ~5e-4."""
+    Two things make the comparison well-posed.  (1) The ORACLE is re-synchronised to the product's state before each step: a
+    free-running comparison of weights is ill-conditioned (Adam's first updates are lr * g / (|g| + 1e-7): a weight whose
+    gradient is float32 noise steps +lr in one implementation and -lr in the other).  (2) The oracle's backward is given the
+    LeakyReLU branch decisions the product took in that step (oracle.step `force`): the gradient is discontinuous where a
+    pre-activation crosses zero, about one of the 2 M units of a generator pass sits within float32 rounding of the kink, and
+    that one unit moved a whole tensor's relative L2 error to 2e-3 before the branches were shared (round 3: measured
+    2.0e-3 on the generator's Dense kernel at celeba64 / batch 8 / step 2, 9.7e-6 with the branches shared --
+    test_gradients_match_oracle_on_the_same_relu_branches).  With both in place the slots agree to a relative L2 error of 1e-4."""
     from helpers import sync_oracle_from_product
     gan, st, reals, rng = _make(arch, B, std, seed=5)
     hp = dict(S.DEFAULT_HP, global_batch_size=B)
@@ -121,9 +124,8 @@ def test_real_architecture_training_steps_match_oracle(arch, B, std, steps):
             sync_oracle_from_product(st, gan)               # the product itself is NOT reloaded
         rnd = S.draw_randomness(arch, B, rng, np.float64)
         r = rng.uniform(-1, 1, size=reals.shape)
-        st32, _, _ = S.train_on_batch(to_float32_state(st), r.astype(np.float32), to_float32_randomness(rnd), hp)   # the yardstick
-        st, met, _ = S.train_on_batch(st, r, rnd, hp)
         got = dict(zip(gan.metrics_names, gan.train_on_batch(r.astype(np.float32), randomness=rnd)))
+        st, met, _ = S.train_on_batch(st, r, rnd, hp, force=product_lrelu_branches(gan, B))
         for k in ("disc_loss", "gen_loss", "gp_term", "real_scores", "fake_scores"):
             assert abs(got[k] - met[k]) < 1e-3 * (abs(met[k]) + 0.1), (it, k, got[k], met[k])
         assert int(gan.n_img) == (it + 1) * B == st["n_img"] and int(gan.n_batches) == it + 1 == st["n_batches"]
@@ -143,18 +145,15 @@ def test_real_architecture_training_steps_match_oracle(arch, B, std, steps):
                 worst[key + "_w_bad_frac"] = max(worst.get(key + "_w_bad_frac", 0.0), bad)
                 assert bad <= 0.02, (key, name, a.shape, bad)
             for slot in ("m", "v"):
-                for a, b, b32 in zip(product_slots(model, slot), oracle_grad_list(st[f"{key}_{slot}"]), oracle_grad_list(st32[f"{key}_{slot}"])):
+                for a, b in zip(product_slots(model, slot), oracle_grad_list(st[f"{key}_{slot}"])):
                     b = np.asarray(b, dtype=np.float64).reshape(a.shape)
                     e = float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
                     worst[key + "_" + slot] = max(worst.get(key + "_" + slot, 0.0), e)
                     assert e <= (1e-2 if key == "g" else 3e-3), (key, slot, a.shape, e, it)
-                    # ... and beside the elementwise bound the per-tensor relative L2 error: 2e-3 (generator; slots after a
-                    # BatchNorm backward over a batch of 4-8) / 4e-4 (critic), or 3 x what the float32 oracle does from the
-                    # same state (measured: generator Dense kernel 2.0e-3 ... 2.4e-3 on the HIP path)
-                    l2, l32 = rel_l2(a, b), rel_l2(np.asarray(b32, np.float64).reshape(a.shape), b)
-                    worst[key + "_" + slot + "_l2"] = max(worst.get(key + "_" + slot + "_l2", 0.0), l2)
-                    worst[key + "_" + slot + "_l2_f32oracle"] = max(worst.get(key + "_" + slot + "_l2_f32oracle", 0.0), l32)
-                    assert l2 <= max(2e-3 if key == "g" else 4e-4, 3.0 * l32), (key, slot, a.shape, l2, l32, it)
+                    if a.size > 1:          # (the critic's Dense bias is a scalar residue of +-B/gbs terms: 1.7e-4 relative by itself)
+                        l2 = rel_l2(a, b)
+                        worst[key + "_" + slot + "_l2"] = max(worst.get(key + "_" + slot + "_l2", 0.0), l2)
+                        assert l2 <= 1e-4, (key, slot, a.shape, l2, it)
     print(f"{arch} B={B} {steps} steps: worst deviations {worst}")
 
 
@@ -169,7 +168,8 @@ def test_gradients_match_oracle_on_the_same_relu_branches(arch, B, std, steps, s
     error appears at one layer's d(beta), 20x smaller in its d(gamma), and rides down the stack from there; the layers above
     it agree to 1e-5: tests/step_error.py).  Here the oracle's backward is given the branch decisions the product actually
     took (oracle.step `force`): both then differentiate the same piecewise-linear function, and every gradient of both
-    networks agrees to a relative L2 error of 1e-4 with cosine 1 - 1e-8 -- on consecutive steps with the real learning rate,
+    networks agrees to a relative L2 error of 5e-5 (generator; measured <= 9.7e-6) / 1e-5 (critic; measured <= 1.1e-6) with
+    cosine 1 - 1e-9 -- on consecutive steps with the real learning rate,
     the oracle re-synchronised to the product's state before each (the gradients are read back from Adam's first moment)."""
     from helpers import sync_oracle_from_product
     gan, st, reals, rng = _make(arch, B, std, seed=seed)
@@ -195,7 +195,7 @@ def test_gradients_match_oracle_on_the_same_relu_branches(arch, B, std, steps, s
                     continue
                 l2, c = rel_l2(a, b), 1.0 - cosine(a, b)
                 worst[key] = (max(worst[key][0], l2), max(worst[key][1], c))
-                assert l2 <= 1e-4 and c <= 1e-8, (arch, key, i, a.shape, it, l2, c)
+                assert l2 <= (5e-5 if key == "g" else 1e-5) and c <= 1e-9, (arch, key, i, a.shape, it, l2, c)
     print(f"[same branches] {arch} B={B} {steps} step(s): worst rel-L2 / (1-cos): generator {worst['g'][0]:.1e} / {worst['g'][1]:.0e}, "
           f"critic {worst['d'][0]:.1e} / {worst['d'][1]:.0e}")
 

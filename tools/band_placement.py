@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""Where and when the waves of blur_band_t_kernel ran, from a -DBLUR_BAND_STAMP build
-(tools/build_variant.sh band_stamp blur.hip -DBLUR_BAND_STAMP; BGAN_HIP_LIB=tools/_build/libbgan_band_stamp.so).
+"""Where and when the waves of blur_band_t_kernel ran, from a -DBG_DIAG -DBLUR_BAND_STAMP build
+(tools/build_variant.sh band_stamp blur.hip -DBG_DIAG -DBLUR_BAND_STAMP; BGAN_HIP_LIB=tools/_build/libbgan_band_stamp.so).
 Prints waves per (XCC, SE, CU, SIMD) slot, the span of the launch and the start times of the workgroups.
 Usage: band_placement.py B H W C sigma"""
 import collections

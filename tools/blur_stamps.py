@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Phase timeline of blur_strip_kernel from a -DBLUR_STRIP_STAMP build (tools/build_variant.sh stamp blur.hip -DBLUR_STRIP_STAMP;
+"""Phase timeline of blur_strip_kernel from a -DBG_DIAG -DBLUR_STRIP_STAMP build (tools/build_variant.sh stamp blur.hip -DBG_DIAG -DBLUR_STRIP_STAMP;
 BGAN_HIP_LIB=tools/_build/libbgan_stamp.so): mean cycles per phase and iteration over all workgroups.
 Usage: blur_stamps.py B H W C sigma"""
 import os
