@@ -30,31 +30,12 @@ def _deps():
     return hdrs
 
 
-ASAN_DIR = os.path.join(os.path.dirname(HERE), "tools", "_build", "asan")
-ASAN_LIB = os.path.join(ASAN_DIR, "libbgan_hip_asan.so")
-# HOST code only (--cuda-host-only: no device code objects, so nothing can be launched from this build -- it exists for the
-# argument checks, planners and policy maths), instrumented; seconds to compile
-ASAN_FLAGS = ["--offload-arch=gfx950", "--cuda-host-only", "-O1", "-g", "-fPIC", "-std=c++17", "-ffp-contract=off", "-w",
-              "-fsanitize=address", "-shared-libasan"]
-
-
-def asan_runtime():
-    """Path of clang's shared AddressSanitizer runtime (to LD_PRELOAD into the python that dlopens the instrumented library)."""
-    r = subprocess.run([HIPCC, "-print-file-name=libclang_rt.asan-x86_64.so"], capture_output=True, text=True)
-    p = r.stdout.strip()
-    if not os.path.isabs(p):
-        import glob
-        c = glob.glob("/opt/rocm/lib/llvm/lib/clang/*/lib/linux/libclang_rt.asan-x86_64.so")
-        p = c[0] if c else p
-    return p
-
-
-def build_lib(force=False, verbose=True, asan=False):
-    """asan=True: the AddressSanitizer build of the HOST side of the C ABI (argument checks, planners, policy maths) for the
-    CPU tests -- never run on the GPU box."""
+def build_lib(force=False, verbose=True, flags=None, lib=None, odir=None, post_compile=None):
+    """flags / lib / odir: an alternative build of the same sources (tools/host_sanitizer_build.py: the host-only build the CPU
+    tests run under a sanitizer); post_compile(objs) may append objects before the link."""
     objs, jobs = [], []
     hdr_time = max(os.path.getmtime(h) for h in _deps())
-    flags, lib, odir = (ASAN_FLAGS, ASAN_LIB, ASAN_DIR) if asan else (FLAGS, LIB, CSRC)
+    flags, lib, odir = flags or FLAGS, lib or LIB, odir or CSRC
     os.makedirs(odir, exist_ok=True)
     for s in SOURCES:
         src = os.path.join(CSRC, s)
@@ -74,23 +55,13 @@ def build_lib(force=False, verbose=True, asan=False):
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         list(ex.map(run, jobs))
-    if asan and (jobs or not os.path.exists(lib)):
-        # every host object refers to the device code object of its translation unit (__hip_fatbin_<hash>), which a host-only
-        # compile does not produce: empty blobs keep the module constructors linkable; nothing is ever launched from this build
-        syms = set()
-        for o in objs:
-            out = subprocess.run(["nm", "-u", o], capture_output=True, text=True).stdout
-            syms.update(l.split()[-1] for l in out.splitlines() if "__hip_fatbin_" in l)
-        stub_c, stub_o = os.path.join(odir, "fatbin_stub.c"), os.path.join(odir, "fatbin_stub.o")
-        with open(stub_c, "w") as f:
-            for sym in sorted(syms):
-                f.write(f'__attribute__((section(".hip_fatbin"), aligned(4096))) const char {sym}[4096] = {{0}};\n')
-        run(["gcc", "-fPIC", "-c", stub_c, "-o", stub_o])
-        objs.append(stub_o)
+    link_extra = []
+    if post_compile is not None and (jobs or not os.path.exists(lib)):
+        link_extra = post_compile(objs, run)
     if jobs or not os.path.exists(lib):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *(["-fsanitize=address", "-shared-libasan"] if asan else []), *objs, "-ldl", "-o", lib])
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *link_extra, *objs, "-ldl", "-o", lib])
     return lib
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, asan="--asan" in sys.argv))
+    print(build_lib(force="--force" in sys.argv))

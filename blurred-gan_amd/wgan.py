@@ -484,7 +484,11 @@ def gradient_penalty(discriminator, reals, fakes, alpha=None):
     D.forward(ctx, xhat, training=False)
     g = D.backward(ctx, ops.fill(torch.empty(B, 1, dtype=torch.float32, device=dev), 1.0), need_dx=True, need_dw=False)
     n = ops.row_norm(g, torch.empty(B, dtype=torch.float32, device=dev))
-    return ((n - 1.0) ** 2).mean()
+    # mean((n - 1)^2) by the loss kernel itself (metric slot 5 of bg_wgangp_d_loss), not by torch arithmetic
+    zero = ops.fill(torch.empty(B, dtype=torch.float32, device=dev), 0.0)
+    scratch, met = torch.empty(2, B, dtype=torch.float32, device=dev), torch.empty(8, dtype=torch.float32, device=dev)
+    ops.wgangp_d_loss(zero, zero, n, 1.0, 0.0, 0.0, 1.0, scratch[0], scratch[1], met)
+    return met[5]
 
 
 class WGANGP(WGAN):

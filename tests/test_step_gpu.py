@@ -233,6 +233,19 @@ def test_celeba64_batch256_step_matches_oracle():
     assert abs(got["gen_loss"] - gm["gen_loss"]) < 1e-4 * max(1, abs(gm["gen_loss"]))
 
 
+def test_gradient_penalty_value_function():
+    """The reference's module-level gradient_penalty(discriminator, reals, fakes) (wgan.py:234-246), value only, on the HIP
+    kernels (critic forward / data gradient / blur^T / per-sample norms / the loss kernel's mean) against the oracle."""
+    from blurred_gan_amd.wgan import gradient_penalty
+    arch, B = "tiny", 5
+    gan, st, reals, rng = _make(arch, B, 1.2)
+    fakes = rng.uniform(-1, 1, size=reals.shape)
+    alpha = rng.uniform(size=B)
+    want = S.gradient_penalty(st, reals, fakes, alpha, want_grads=False)[0]
+    got = float(gradient_penalty(gan.discriminator, torch.from_numpy(reals), torch.from_numpy(fakes), torch.from_numpy(alpha)))
+    assert abs(got - want) < 1e-4 * max(1.0, abs(want)), (got, want)
+
+
 def test_vector_loss_quirk_switch():
     """Q1 on/off changes the critic gradient exactly by the documented factor on the W + GP part."""
     arch, B = "tiny", 4
