@@ -131,6 +131,7 @@ class Net:
         self.store = store
         self.device = store.device
         self.blur = None
+        self.capture_branches = None     # test instrumentation (gp_second_order_merged): a list collects the x-hat rows' LeakyReLU signs
         self.stages: List[Stage] = []
         self.in_shape = tuple(flat_layers[0][1])
         cur = None
@@ -370,14 +371,15 @@ class Net:
 
     # ------------------------------------------------------------------ backward
     def backward(self, ctx: Context, dout, need_dx=False, need_dw=True, beta=0.0, scale=1.0, reducer=None, dw_rows=None,
-                 dx_rows=None):
+                 dx_rows=None, defer_conv_dw=False):
         """Reverse pass of the last ``forward`` on ``ctx``.  Weight gradients go to ``store.grad``
         (= beta*old + scale*new).  Returns d(loss)/d(net input) *before* the blur (or None).
         ``reducer`` (dist.GradReducer): this pass completes the gradients, so each stage's slice of the flat buffer is
         handed to the bucketed all-reduce as soon as its kernels are enqueued.
         ``dw_rows``: weight gradients from the first dw_rows samples only; ``dx_rows`` = (lo, hi): the input gradient (last
         data-gradient + blur^T) for those samples only -- the merged critic pass wants weights from [fakes; reals] and the
-        image gradient of x-hat."""
+        image gradient of x-hat.  ``defer_conv_dw``: the conv filter gradients are left to ``gp_second_order_merged`` (bias
+        and Dense gradients are still taken here)."""
         st_ = self.store
         if need_dw:
             st_.ensure_opt_state()
@@ -444,9 +446,10 @@ class Net:
                     ops.gemm(xw, dzw, dW, K, N, WB, transA=True, beta=beta, scale=scale)
                     rows = WB
                 elif st.kind == "conv":
-                    Bc, H, W, Ci = xw.shape
-                    nb = ops.conv2d_bwd_filter_workspace_bytes(Bc, H, W, Ci, lin.filters, lin.k, lin.stride)
-                    ops.conv2d_bwd_filter(xw, dzw, dW, lin.k, lin.stride, beta, scale, self.workspace(nb) if nb else None)
+                    if not defer_conv_dw:
+                        Bc, H, W, Ci = xw.shape
+                        nb = ops.conv2d_bwd_filter_workspace_bytes(Bc, H, W, Ci, lin.filters, lin.k, lin.stride)
+                        ops.conv2d_bwd_filter(xw, dzw, dW, lin.k, lin.stride, beta, scale, self.workspace(nb) if nb else None)
                     rows = dzw.numel() // lin.filters
                 else:
                     Bc, H, W, Ci = dzw.shape          # conv input side == ConvT output
@@ -457,7 +460,7 @@ class Net:
                     N = st.out_shape[-1]
                     ws = self.workspace(ops.colsum_workspace_bytes(rows, N))
                     ops.colsum(dzw, st_.grad_of(lin, "bias"), rows, N, ws, beta=beta, scale=scale)
-                if reducer is not None:
+                if reducer is not None and not (defer_conv_dw and st.kind == "conv"):
                     # Under the SyncBN overlap a slice is NOT handed over right away: ready() may flush a 16 MB bucket onto the
                     # collective stream, and the small statistics exchange of the next stage down, issued one iteration later,
                     # would queue behind it -- back on the critical path.  The slice waits until that exchange is in flight.
@@ -534,6 +537,45 @@ class Net:
         return din
 
     # ------------------------------------------------------------------ GP second order
+    def gp_second_order_merged(self, ctx: Context, lo, hi, reducer=None):
+        """The second order of the penalty AND the filter gradients of the whole merged critic pass, one launch per layer.
+
+        The first-order gradient of layer i is wgrad(x = a_{i-1}[rows of fakes, reals], dy = dz_i[same rows]); the penalty adds
+        wgrad(x = delta-bar_{i-1}, dy = zeta_i) over the x-hat rows (GP derivation step 2).  Rows are the
+        contraction index, so with delta-bar_{i-1} written INTO the x-hat rows [lo, hi) of the pass's activation buffer a_{i-1}
+        -- dead after the backward except for their signs, which the linearised forward consumes as it overwrites them in
+        place -- both are ONE filter gradient over all 3B rows of (a_{i-1}, dz_i): five launches (and their slab reduces)
+        fewer per D-step, and the remaining ones run at 3B rows instead of 2B + B.  The caller has put delta-bar_0 into
+        ctx.a0[lo:hi] and run ``backward(..., defer_conv_dw=True)``."""
+        st_ = self.store
+        st_.ensure_opt_state()
+        B3, Bh = ctx.B, hi - lo
+        for i, st in enumerate(self.stages):
+            lin = st.lin
+            last = i == len(self.stages) - 1
+            if st.kind == "conv" and st.fusable_grad and not last:
+                xin = ctx.xin[i]                                  # [3B, ...]: activations of [fakes; reals], delta-bar_{i-1} in the x-hat rows
+                _, H, W, Ci = xin.shape
+                nb = ops.conv2d_bwd_filter_workspace_bytes(B3, H, W, Ci, lin.filters, lin.k, lin.stride)
+                ops.conv2d_bwd_filter(xin, ctx.dz[i].view(B3, *st.out_shape), st_.grad_of(lin, "kernel"), lin.k, lin.stride, 0.0, 1.0,
+                                      self.workspace(nb) if nb else None)
+                if reducer is not None:
+                    reducer.ready(*st_.train_range(lin, st.bn))
+                ah = ctx.a[i][lo:hi]
+                if self.capture_branches is not None:            # test instrumentation: the signs about to be overwritten
+                    self.capture_branches.append((ah > 0).cpu().numpy())
+                epi = self._epi(False, Bh, H, W, Ci, lin.filters, lin.k, lin.stride, EPI_MUL_GRAD, ref=ah, alpha=st.alpha)
+                ops.conv2d_fwd(xin[lo:hi], self.store.transposed_kernel(lin), ah, lin.k, lin.stride, epi)   # in place: ref == out
+            elif st.kind == "dense" and last and st.out_shape == (1,) and st.bn is None and st.act is None:
+                K = st.in_shape[0]
+                ws = self.workspace(ops.colsum_workspace_bytes(Bh, K))
+                ops.colsum(ctx.xin[i][lo:hi].reshape(Bh, K), st_.grad_of(lin, "kernel").view(K), Bh, K, ws, beta=1.0, scale=1.0)
+                if reducer is not None:
+                    reducer.ready(*st_.train_range(lin, st.bn))
+            else:
+                raise NotImplementedError("gradient penalty second order supports the reference critic shape only: "
+                                          "[Conv2D+LeakyReLU(+Dropout)]* -> Flatten -> Dense(1) (demo_celeba.py:96-124)")
+
     def gp_second_order(self, ctx: Context, v0, reducer=None):
         """SURVEY.md 8a, GP derivation step 2: one linearised forward of the critic on ``v0`` with the
         LeakyReLU masks of the x-hat pass frozen, plus one wgrad per conv layer against the zeta_i kept by

@@ -103,7 +103,8 @@ class WGAN:
 
     def __init__(self, generator: Sequential, discriminator: Sequential, hyperparams: "WGAN.HyperParameters",
                  config: TrainingConfig, *args, reproduce_vector_loss_quirk: bool = True, sync_metrics: bool = True,
-                 sync_batchnorm: bool = True, merge_critic_passes: bool = True, gp_zero_norm_guard: bool = False, **kwargs):
+                 sync_batchnorm: bool = True, merge_critic_passes: bool = True, gp_zero_norm_guard: bool = False,
+                 merge_gp_filter_gradients: bool = True, **kwargs):
         self.hparams = hyperparams
         if dist.world_size() > 1 and int(hyperparams.global_batch_size) != int(hyperparams.batch_size) * dist.world_size():
             import warnings
@@ -146,6 +147,9 @@ class WGAN:
         self.sync_batchnorm = sync_batchnorm  # DP: generator BN statistics over the global batch (False = per replica)
         # critic step: [fakes; reals] and x-hat in one 3B-sample forward / backward (False: two passes, as the reference orders them)
         self.merge_critic_passes = merge_critic_passes and not os.environ.get("BGAN_NO_MERGED_CRITIC")
+        # the penalty's second-order filter gradients ride in the merged pass's own filter-gradient launches
+        # (engine.Net.gp_second_order_merged); needs the merged critic pass
+        self.merge_gp_filter_gradients = merge_gp_filter_gradients and not os.environ.get("BGAN_NO_MERGED_GP_WGRAD")
         # a sample whose critic input-gradient is exactly zero makes the penalty's second-order seed (n-1)/n * g = NaN, in the
         # reference too (tf.norm's gradient at 0); True takes the subgradient 0 for that sample instead
         self.gp_zero_norm_guard = gp_zero_norm_guard
@@ -315,14 +319,26 @@ class WGAN:
             ds3 = self._buf("ds3", (3 * B,))
             ops.fill(ds3[2 * B:], 1.0)
             ops.wgangp_d_loss(fs, rs, None, inv_gbs, gp_c, e_d, vs, ds3[:B], ds3[B:2 * B], met)      # seeds only; metrics below
+            one_wgrad = self.merge_gp_filter_gradients
             g = D.backward(c3, ds3.view(3 * B, 1), need_dx=True, need_dw=True, beta=0.0, scale=1.0, dw_rows=2 * B,
-                           dx_rows=(2 * B, 3 * B))
+                           dx_rows=(2 * B, 3 * B), defer_conv_dw=one_wgrad)
             norms = ops.row_norm(g, self._buf("gp_norms", (B,)))
             ops.wgangp_d_loss(fs, rs, norms, inv_gbs, gp_c, e_d, vs, ds3[:B], ds3[B:2 * B], met)    # same seeds, full metrics
             coef = vs * float(hp.gp_coefficient) * 2.0 / float(B * dist.world_size())
-            gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)), self.gp_zero_norm_guard)
-            v0 = D.apply_blur(gbar, self._buf("v0", tuple(g.shape))) if D.blur is not None else gbar
-            D.gp_second_order(c3.rows(2 * B, 3 * B), v0, reducer=red)
+            if one_wgrad:
+                # delta-bar_0 goes into the x-hat rows of the pass's (blurred) input buffer, where the layer-1 filter gradient
+                # reads it beside the activations of [fakes; reals]; g itself lives in those rows and is dead after the seed
+                hat0 = c3.a0[2 * B:3 * B]
+                if D.blur is not None:
+                    gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)), self.gp_zero_norm_guard)
+                    D.apply_blur(gbar, hat0)
+                else:
+                    ops.gp_seed(g, norms, coef, hat0.view(g.shape), self.gp_zero_norm_guard)      # g is the net's own input-gradient buffer
+                D.gp_second_order_merged(c3, 2 * B, 3 * B, reducer=red)
+            else:
+                gbar = ops.gp_seed(g, norms, coef, self._buf("gbar", tuple(g.shape)), self.gp_zero_norm_guard)
+                v0 = D.apply_blur(gbar, self._buf("v0", tuple(g.shape))) if D.blur is not None else gbar
+                D.gp_second_order(c3.rows(2 * B, 3 * B), v0, reducer=red)
         else:
             cfr = D.context(2 * B, "fr")
             s2 = D.forward(cfr, [fakes, reals], training=True, masks=masks, seed=seed).view(2 * B)

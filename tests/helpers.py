@@ -142,9 +142,17 @@ def check_grad_quality(prod, ora, key, label, ora32=None, l2_bound=None, cos_bou
     return table
 
 
+def arm_branch_capture(gan):
+    """Call BEFORE train_on_batch: the merged second-order pass overwrites the x-hat rows of the critic's activations in place
+    (engine.Net.gp_second_order_merged); with this list armed it first copies their signs out (instrumentation only -- the
+    arithmetic path is the default one)."""
+    gan.discriminator.net().capture_branches = []
+
+
 def product_lrelu_branches(gan, B):
     """LeakyReLU branch decisions (1 / alpha per unit) the product took in its LAST train_on_batch, read back from the
-    activations its passes left in their contexts (merged critic pass "fr3": rows [0, B) fakes, [B, 2B) reals, [2B, 3B) x-hat;
+    activations its passes left in their contexts (merged critic pass "fr3": rows [0, B) fakes, [B, 2B) reals, [2B, 3B) x-hat
+    -- those from the signs captured by arm_branch_capture when the merged second-order pass has overwritten them;
     G-step: generator "g", critic "hat").  Shaped for oracle.step's ``force`` argument.  A unit that Dropout zeroed reads as
     alpha here and is multiplied by its keep mask (0) in the oracle's backward anyway."""
     G, D = gan.generator.net(), gan.discriminator.net()
@@ -157,5 +165,12 @@ def product_lrelu_branches(gan, B):
                 out.append(np.where(a.detach().cpu().numpy() > 0, 1.0, float(st.alpha)))
         return out
     c3 = D.context(3 * B, "fr3", drop_rows=2 * B)
-    return {"fake": masks(D, c3, 0, B), "real": masks(D, c3, B, 2 * B), "hat": masks(D, c3, 2 * B, 3 * B),
+    if D.capture_branches:
+        alphas = [float(st.alpha) for st in D.stages if st.act == "lrelu"]
+        hat = [np.where(s, 1.0, a) for s, a in zip(D.capture_branches, alphas)]
+        D.capture_branches = None
+    else:
+        assert not getattr(gan, "merge_gp_filter_gradients", False) or not gan.uses_gradient_penalty, "arm_branch_capture(gan) first"
+        hat = masks(D, c3, 2 * B, 3 * B)
+    return {"fake": masks(D, c3, 0, B), "real": masks(D, c3, B, 2 * B), "hat": hat,
             "g": masks(G, G.context(B, "g")), "d_gstep": masks(D, D.context(B, "hat"))}

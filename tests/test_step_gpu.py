@@ -8,7 +8,7 @@ import torch
 
 from oracle import step as S
 from helpers import (load_oracle_weights, product_grads, product_slots, oracle_grad_list, oracle_weight_list, check_grad_quality, rel_l2,
-                     to_float32_state, to_float32_randomness, product_lrelu_branches, cosine)
+                     to_float32_state, to_float32_randomness, product_lrelu_branches, arm_branch_capture, cosine)
 
 pytestmark = pytest.mark.gpu
 
@@ -124,6 +124,7 @@ def test_real_architecture_training_steps_match_oracle(arch, B, std, steps):
             sync_oracle_from_product(st, gan)               # the product itself is NOT reloaded
         rnd = S.draw_randomness(arch, B, rng, np.float64)
         r = rng.uniform(-1, 1, size=reals.shape)
+        arm_branch_capture(gan)
         got = dict(zip(gan.metrics_names, gan.train_on_batch(r.astype(np.float32), randomness=rnd)))
         st, met, _ = S.train_on_batch(st, r, rnd, hp, force=product_lrelu_branches(gan, B))
         for k in ("disc_loss", "gen_loss", "gp_term", "real_scores", "fake_scores"):
@@ -183,6 +184,7 @@ def test_gradients_match_oracle_on_the_same_relu_branches(arch, B, std, steps, s
         rnd = S.draw_randomness(arch, B, rng, np.float64)
         r = rng.uniform(-1, 1, size=reals.shape)
         m_old = {k: [a.astype(np.float64) for a in product_slots(mod, "m")] for k, mod in (("g", gan.generator), ("d", gan.discriminator))}
+        arm_branch_capture(gan)
         gan.train_on_batch(r.astype(np.float32), randomness=rnd)
         st, met, aux = S.train_on_batch(st, r, rnd, hp, force=product_lrelu_branches(gan, B))
         for key, mod in (("d", gan.discriminator), ("g", gan.generator)):
@@ -244,6 +246,26 @@ def test_gradient_penalty_value_function():
     want = S.gradient_penalty(st, reals, fakes, alpha, want_grads=False)[0]
     got = float(gradient_penalty(gan.discriminator, torch.from_numpy(reals), torch.from_numpy(fakes), torch.from_numpy(alpha)))
     assert abs(got - want) < 1e-4 * max(1.0, abs(want)), (got, want)
+
+
+@pytest.mark.parametrize("arch,B", [("tiny", 5), ("mnist", 6), ("celeba64", 4)])
+def test_merged_penalty_filter_gradients_equal_the_separate_launches(arch, B):
+    """engine.Net.gp_second_order_merged (the penalty's second-order filter gradients taken in the SAME launches as the merged
+    critic pass's own, over all 3B rows) against the separate launches it replaced (WGAN(merge_gp_filter_gradients=False)), and
+    against the two-pass critic (merge_critic_passes=False): the same critic gradients up to summation order."""
+    ref = None
+    for kw in (dict(), dict(merge_gp_filter_gradients=False), dict(merge_critic_passes=False)):
+        gan, st, reals, rng = _make(arch, B, 1.0, seed=4, **kw)
+        rnd = S.draw_randomness(arch, B, rng, np.float64)
+        gan.discriminator.optimizer.learning_rate = 0.0
+        gan.generator.optimizer.learning_rate = 0.0
+        gan.train_on_batch(reals.astype(np.float32), randomness=rnd)
+        grads = product_grads(gan.discriminator)
+        if ref is None:
+            ref = grads
+            continue
+        for a, b in zip(grads, ref):
+            assert rel_l2(a, b) < 2e-6 or not np.any(b), (kw, a.shape, rel_l2(a, b))
 
 
 def test_vector_loss_quirk_switch():
