@@ -821,7 +821,11 @@ int plan_splitk(const GatherParams& p, int bm, int bn, int bk) {
   for (int i = 0; i < p.nphase; ++i) maxpos = std::max(maxpos, p.ph[i].Ha * p.ph[i].Wa);
   const bool skipping = maxpos <= 16 && p.B >= bm && p.B % bm == 0;      // 8x8 maps lose a quarter of their taps at most: not worth it (G3: 0.22 -> 0.26 ms)
   if (skipping && wgs >= min_wgs && wgs <= 2 * min_wgs && min_steps >= 64) {
-    const int ks = (int)std::min<long>(4, 4L * min_wgs / wgs);
+    // round 3: the cost-sorted snake order balances the CUs of ONE round of resident workgroups, so the split only has to fill
+    // that round (1024 slots), not make short workgroups: 768 tiles run unsplit (D4 forward of the merged critic pass
+    // 0.188 -> 0.159 ms), 1024 unsplit (G2 data gradient 0.185 -> 0.173), 512 in two halves as before.  BG_SPLITK_OLD=1: round-2 rule
+    static const int old_rule = getenv("BG_SPLITK_OLD") ? 1 : 0;
+    const int ks = old_rule ? (int)std::min<long>(4, 4L * min_wgs / wgs) : (int)std::max<long>(1, 2L * min_wgs / wgs);
     return std::max(1, std::min(ks, min_steps / 32));
   }
   if (wgs >= 2 * min_wgs || min_steps < 32) return 1;

@@ -1312,7 +1312,9 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
     // ~3 workgroups per CU; the tap-grouped kernel (3 resident per CU) measured best at two full rounds (G5: 0.30 -> 0.27 ms)
     const int tgt = tgt_env ? tgt_env : (pl.taps_in_grid == 2 && M >= 200000 ? 1536 : 768);
     want = std::max(1L, (tgt + base - 1) / base);
-    want = std::min(want, std::max(1L, steps / 4));               // at least 4 K-steps per workgroup
+    // at least 4 K-steps per workgroup; 8 on the tap-skipping small maps, where about half of them are skipped and every
+    // split costs a 25-tap slab (critic 128->256 on a 4x4 map at batch 128: 16 splits = 52 MB of slabs, 55 us; 8 splits 47 us)
+    want = std::min(want, std::max(1L, steps / (skipping ? 8 : 4)));
     if ((size_t)kk * Ci * Co * sizeof(float) > (8u << 20)) want = std::min(want, 2L);   // big slabs: the reduce pass costs more than idle CUs
   } else {
     // Pixel split from a cost model instead of a fixed workgroup target: the grid runs in ROUNDS of (workgroups resident per
