@@ -1,0 +1,63 @@
+"""N3 on the GPU: the metric feeders of reference callbacks.py:138-206 driven by a real `fit()` of the HIP path --
+`model.images` (the fakes and reals of the D-step, wgan.py:103) go through the demo's preprocessing (normalise to [0, 1],
+grayscale -> RGB, NHWC -> NCHW, demo_mnist.py:180-184) into SWDMetric / FIDMetric, and the recorded results equal the metrics
+recomputed from those very images with the same seeds.  (The Frechet distance's feature extractor is injected: the reference's
+Inception-v3 is a tfhub download.)"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _preprocess(images):
+    from blurred_gan_amd import utils
+    x = utils.normalize_images(images)                      # [-1, 1] -> [0, 1]  (utils.py:50-52)
+    if x.shape[-1] == 1:
+        x = x.repeat(1, 1, 1, 3)                            # tf.image.grayscale_to_rgb
+    return utils.NHWC_to_NCHW(x) * 255.0                    # the SWD code works on 0..255 NCHW minibatches
+
+
+def test_swd_and_fid_feeders_on_a_real_fit(tmp_path):
+    import blurred_gan_amd as bg
+    from blurred_gan_amd import models, callbacks, metrics, sliced_wasserstein as sw
+    bg.set_seed(11)
+    arch, B, nb = "mnist", 8, 4
+    gen, disc = models.DCGANGenerator(arch=arch), models.DCGANDiscriminator(arch=arch)
+    hp = bg.BlurredWGANGP.HyperParameters(initial_blur_std=1.0, global_batch_size=B, batch_size=B)
+    gan = bg.BlurredWGANGP(gen, disc, hp, bg.TrainingConfig(log_dir=str(tmp_path / "log")))
+    g = torch.Generator().manual_seed(5)
+    data = [torch.rand(B, 28, 28, 1, generator=g) * 2 - 1 for _ in range(nb)]
+
+    seen = []                                               # what the feeders saw, captured by a third callback
+
+    class Tap(callbacks.Callback):
+        def on_batch_end(self, batch, logs):
+            fakes, reals = self.model.images
+            seen.append((_preprocess(reals).cpu().numpy().copy(), _preprocess(fakes).cpu().numpy().copy()))
+
+    proj = np.random.RandomState(0).normal(size=(3 * 28 * 28, 12))
+    feats = lambda imgs: np.asarray(imgs, np.float64).reshape(len(imgs), -1) @ proj / 255.0
+    swd_cb = callbacks.SWDMetricCallback(_preprocess, num_samples=2 * B, every_n_examples=2 * B, seed=3)
+    fid_cb = callbacks.FIDMetricCallback(_preprocess, feats, num_samples=2 * B, every_n_examples=2 * B)
+    gan.fit(data, epochs=1, callbacks=[Tap(), swd_cb, fid_cb])
+    assert int(gan.n_batches) == nb and len(seen) == nb
+    assert len(swd_cb.results) >= 1 and len(fid_cb.results) >= 1
+    first = swd_cb.results[0]
+    assert set(first) == {"SWDx1e3_28", "SWDx1e3_avg"} and all(np.isfinite(v) and v >= 0 for v in first.values())
+    assert np.isfinite(fid_cb.results[0]) and fid_cb.results[0] >= 0
+    # recompute from the captured images: the feeders start recording at the first batch (starting_from = -num_samples)
+    m = metrics.SWDMetric(seed=3)
+    f = metrics.FIDMetric(feats)
+    for reals, fakes in seen[:2]:
+        m.update_state(reals, fakes)
+        f.update_state(reals, fakes)
+    want = m.results()
+    for k in first:
+        assert abs(first[k] - want[k]) <= 1e-9 * max(1.0, abs(want[k])), (k, first[k], want[k])
+    assert abs(fid_cb.results[0] - f.result()) <= 1e-9 * max(1.0, abs(f.result()))
+    # real against real is (statistically) closer than real against fake for an untrained generator
+    same = metrics.SWDMetric(seed=3)
+    for reals, _ in seen[:2]:
+        same.update_state(reals, reals)
+    assert same.results()["SWDx1e3_avg"] < want["SWDx1e3_avg"]
