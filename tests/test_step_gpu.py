@@ -49,28 +49,30 @@ def test_gradients_match_oracle(arch, B, std):
     out = gan.train_on_batch(reals.astype(np.float32), randomness=rnd)
     names = gan.metrics_names
     got = dict(zip(names, out))
+    # This test lets product and oracle take their OWN LeakyReLU branches.  At the small batches that is harmless (a few
+    # thousand units, none near the kink); at batch 64 (12 M critic and 17 M generator units) a unit within float32 rounding of
+    # zero may sit on different branches in the two, and that one unit moves a bias-gradient element by up to 0.5 % and the
+    # generator's tensors by 1e-3 in relative L2 -- the float32 ORACLE deviates from its float64 run by 8e-4 ... 7e-3 there.
+    # So the batch-64 case is held to loose elementwise bounds and to max(5e-3 generator / 2e-3 critic, 3 x the float32 oracle)
+    # in relative L2; the SHARP comparison, with the branches shared, is test_gradients_match_oracle_on_the_same_relu_branches
+    # (same shapes: 9.7e-6 / 1.1e-6).
+    big = B >= 64
     pg = product_grads(gan.discriminator)
     for a, b in zip(pg, oracle_grad_list(dg)):
         scale = max(np.abs(b).max(), 1e-6)
-        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=2e-4 * scale)
+        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=(1e-2 if big else 2e-4) * scale)
     gg, upd, gm = S.generator_grads(st, rnd, hp, B)
     pgg = product_grads(gan.generator)
-    # Generator gradients pass through five BatchNorm backwards (dz - mean(dz) - xhat*mean(dz*xhat)): at batch 64 the
-    # cancellation leaves gradients of 1e-5 whose fp32 evaluation is itself only good to ~1e-2 of their maximum -- the ORACLE
-    # run in float32 deviates from its float64 run by 5e-4...1.4e-2 on this case (the HIP path: 1e-4...3e-3).
-    g_atol = 1e-2 if B >= 64 else 2e-4
     for a, b in zip(pgg, oracle_grad_list(gg)):
         scale = max(np.abs(b).max(), 1e-6)
-        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=g_atol * scale)
-    # the well-conditioned criterion beside the elementwise one: per-variable relative L2 error and cosine; at the batches
-    # where BatchNorm's backward cancels hard the float32 oracle is carried along as the yardstick (helpers.check_grad_quality)
+        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=(1e-2 if big else 2e-4) * scale)
     dg32 = gg32 = None
-    if B >= 64:
+    if big:
         st32, rnd32 = to_float32_state(st), to_float32_randomness(rnd)
         dg32 = oracle_grad_list(S.discriminator_grads(st32, reals.astype(np.float32), rnd32, hp)[0])
         gg32 = oracle_grad_list(S.generator_grads(st32, rnd32, hp, B)[0])
-    check_grad_quality(pg, oracle_grad_list(dg), "d", f"{arch} B={B} critic", dg32)
-    check_grad_quality(pgg, oracle_grad_list(gg), "g", f"{arch} B={B} generator", gg32)
+    check_grad_quality(pg, oracle_grad_list(dg), "d", f"{arch} B={B} critic", dg32, l2_bound=2e-3 if big else None, cos_bound=1e-5 if big else 1e-6)
+    check_grad_quality(pgg, oracle_grad_list(gg), "g", f"{arch} B={B} generator", gg32, l2_bound=5e-3 if big else None, cos_bound=1e-5 if big else 1e-6)
     np.testing.assert_allclose(gan.images[0].cpu().numpy(), fakes, rtol=1e-4, atol=1e-5)
     for k in ("real_scores", "disc_loss", "gp_term", "norm_term"):
         assert abs(got[k] - met[k]) < 1e-4 * max(1, abs(met[k])), (k, got[k], met[k])
@@ -204,31 +206,34 @@ def test_gradients_match_oracle_on_the_same_relu_branches(arch, B, std, steps, s
 
 def test_celeba64_batch256_step_matches_oracle():
     """The exact BASELINE.json configuration (64x64, batch 256, sigma 5 -> 31 taps): one full train_on_batch against the
-    float64 numpy oracle on identical injected randomness (learning rate 0 so the gradients can be read back).  The oracle
-    needs ~1 minute of host time at this batch; the generator tolerance follows test_gradients_match_oracle's B >= 64 case."""
+    float64 numpy oracle on identical injected randomness (learning rate 0 so the gradients can be read back), the oracle
+    differentiating on the LeakyReLU branches the product took (48 M critic units and 67 M generator units per step: a few dozen
+    sit within float32 rounding of the kink, and each one that lands on the other branch moves a bias-gradient element -- a sum
+    of 131 k terms of both signs -- by up to 0.5 %; see test_gradients_match_oracle_on_the_same_relu_branches).  The oracle
+    needs about half a minute of host time at this batch."""
     arch, B, std = "celeba64", 256, 5.0
     gan, st, reals, rng = _make(arch, B, std, seed=9)
     rnd = S.draw_randomness(arch, B, rng, np.float64)
     hp = dict(S.DEFAULT_HP, global_batch_size=B)
-    dg, met, fakes = S.discriminator_grads(st, reals, rnd, hp)
-    gg, upd, gm = S.generator_grads(st, rnd, hp, B)
     gan.discriminator.optimizer.learning_rate = 0.0
     gan.generator.optimizer.learning_rate = 0.0
+    arm_branch_capture(gan)
     got = dict(zip(gan.metrics_names, gan.train_on_batch(reals.astype(np.float32), randomness=rnd)))
-    # critic: each filter-gradient element sums 2 * 256 * Ho * Wo products in float32 (up to 5e5 terms on the first layers):
-    # atol 4e-4 of the variable's largest entry, twice the batch-64 figure (measured worst case here: 2.2e-4)
-    for a, b in zip(product_grads(gan.discriminator), oracle_grad_list(dg)):
-        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=4e-4 * max(np.abs(b).max(), 1e-6))
-    # generator: gradients of 5e-5 left over from the BatchNorm-backward cancellation (see test_gradients_match_oracle); at this
-    # batch 2 of 6.5 M elements of one kernel sit at 1.3e-2 of the variable's maximum -- the float32 ORACLE is 1.4e-2 off
-    # its own float64 run already at batch 64
-    for a, b in zip(product_grads(gan.generator), oracle_grad_list(gg)):
-        np.testing.assert_allclose(a, b.reshape(a.shape), rtol=2e-3, atol=2e-2 * max(np.abs(b).max(), 1e-6))
-    st32, rnd32 = to_float32_state(st), to_float32_randomness(rnd)
-    dg32 = oracle_grad_list(S.discriminator_grads(st32, reals.astype(np.float32), rnd32, hp)[0])
-    gg32 = oracle_grad_list(S.generator_grads(st32, rnd32, hp, B)[0])
-    check_grad_quality(product_grads(gan.discriminator), oracle_grad_list(dg), "d", "celeba64 B=256 critic", dg32)
-    check_grad_quality(product_grads(gan.generator), oracle_grad_list(gg), "g", "celeba64 B=256 generator", gg32)
+    force = product_lrelu_branches(gan, B)
+    dg, met, fakes = S.discriminator_grads(st, reals, rnd, hp, force)
+    gg, upd, gm = S.generator_grads(st, rnd, hp, B, force)
+    worst = {}
+    for key, prod, ora in (("d", product_grads(gan.discriminator), oracle_grad_list(dg)), ("g", product_grads(gan.generator), oracle_grad_list(gg))):
+        for i, (a, b) in enumerate(zip(prod, ora)):
+            b = np.asarray(b, np.float64).reshape(a.shape)
+            # elementwise: each filter-gradient element sums up to 5e5 float32 products; 1e-4 of the variable's largest entry
+            np.testing.assert_allclose(a, b, rtol=2e-3, atol=1e-4 * max(np.abs(b).max(), 1e-6), err_msg=f"{key}{i:02d}")
+            if a.size > 1:
+                l2, c = rel_l2(a, b), 1.0 - cosine(a, b)
+                worst[key] = (max(worst.get(key, (0, 0))[0], l2), max(worst.get(key, (0, 0))[1], c))
+                assert l2 <= 2e-5 and c <= 1e-9, (key, i, a.shape, l2, c)          # measured: generator 3.2e-6, critic 3.7e-6
+    print(f"[same branches] celeba64 B=256: worst rel-L2 / (1-cos): generator {worst['g'][0]:.1e} / {worst['g'][1]:.0e}, "
+          f"critic {worst['d'][0]:.1e} / {worst['d'][1]:.0e}")
     np.testing.assert_allclose(gan.images[0].cpu().numpy(), fakes, rtol=1e-4, atol=1e-5)
     for k in ("real_scores", "disc_loss", "gp_term", "norm_term"):
         assert abs(got[k] - met[k]) < 1e-4 * max(1, abs(met[k])), (k, got[k], met[k])
