@@ -89,6 +89,37 @@ def test_two_ranks_match_single_process_global_batch(tmp_path, arch, B_local):
     np.testing.assert_allclose(s0, sg.state[:sg.n_state].cpu().numpy(), rtol=1e-4, atol=1e-6)      # BN moving statistics
 
 
+def test_c3_global_batch_2048_sharded_over_four_ranks(tmp_path):
+    """BASELINE.json configs[2] (C3) as far as one card goes: the 64x64 stack at the GLOBAL batch of 2048, sharded over 4 ranks
+    of 512 (gloo rendezvous, gradients staged through the host; the box allows 6 processes on its card, the real run is 8 x 256
+    over RCCL) against the single-process step at batch 2048: the all-reduced critic and generator gradients (SyncBN statistics
+    exchanged in the forward AND the backward of the G-step, the [B]-vector quirk scaled by the global batch, the penalty
+    averaged over it) equal the global-batch gradients -- compared as whole flat vectors by relative L2 error (both sides are
+    the HIP path on their own LeakyReLU branches: single elements differ by branch flips, see tests/test_step_gpu.py) -- and
+    the replicas end the step bit-identical."""
+    from helpers import rel_l2, cosine
+    world, arch, B_local = 4, "celeba64", 512
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), arch, B_local), nprocs=world, join=True)
+    gan, reals, rnd = _build(arch, B_local * world, B_local * world)
+    gan.train_on_batch(reals, randomness=rnd)
+    for tag, store in (("d", gan.discriminator.store), ("g", gan.generator.store)):
+        ref = store.grad[:store.n_train].cpu().numpy()
+        got = [np.load(tmp_path / f"{tag}_grad_{r}.npy") for r in range(world)]
+        for r in range(1, world):
+            np.testing.assert_array_equal(got[0], got[r])                   # all-reduced: identical on every rank
+        l2, c = rel_l2(got[0], ref), 1.0 - cosine(got[0], ref)
+        print(f"C3 global batch 2048 over {world} ranks, {tag} gradients: rel-L2 {l2:.1e}, 1-cos {c:.0e}")
+        assert l2 <= (5e-3 if tag == "g" else 1e-3) and c <= 2e-5, (tag, l2, c)
+        thetas = [np.load(tmp_path / f"{tag}_theta_{r}.npy") for r in range(world)]
+        for r in range(1, world):
+            np.testing.assert_array_equal(thetas[0], thetas[r])             # replicas stay in lock step
+    s = [np.load(tmp_path / f"g_state_{r}.npy") for r in range(world)]
+    for r in range(1, world):
+        np.testing.assert_array_equal(s[0], s[r])
+    sg = gan.generator.store
+    np.testing.assert_allclose(s[0], sg.state[:sg.n_state].cpu().numpy(), rtol=2e-4, atol=2e-6)      # BN moving statistics of the global batch
+
+
 def test_abi_communicator_single_rank():
     """include/bgan.h's own RCCL communicator (bg_comm_*): with one rank the SUM all-reduce is the identity, runs on the
     stream it is given and leaves the buffer untouched; the handle is created and destroyed without touching torch.distributed.
