@@ -109,7 +109,7 @@ def test_c3_global_batch_2048_sharded_over_four_ranks(tmp_path):
             np.testing.assert_array_equal(got[0], got[r])                   # all-reduced: identical on every rank
         l2, c = rel_l2(got[0], ref), 1.0 - cosine(got[0], ref)
         print(f"C3 global batch 2048 over {world} ranks, {tag} gradients: rel-L2 {l2:.1e}, 1-cos {c:.0e}")
-        assert l2 <= (5e-3 if tag == "g" else 1e-3) and c <= 2e-5, (tag, l2, c)
+        assert l2 <= (1e-3 if tag == "g" else 1e-4) and c <= 1e-6, (tag, l2, c)     # measured 2.6e-5 / 4.5e-7
         thetas = [np.load(tmp_path / f"{tag}_theta_{r}.npy") for r in range(world)]
         for r in range(1, world):
             np.testing.assert_array_equal(thetas[0], thetas[r])             # replicas stay in lock step
