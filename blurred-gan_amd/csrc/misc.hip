@@ -35,30 +35,32 @@ __global__ __launch_bounds__(kT) void gemm_naive_kernel(const float* __restrict_
   }
 }
 
-// LDS-tiled SGEMM, 64x64 tile, 32-deep steps, 4x4 outputs per thread (generator's Dense(100 -> 8192) and its
-// weight gradient).  Small problem (0.4 GFLOP, K = 100 or the batch): what it waits for is the global -> LDS round trip of
-// every step, so the steps are deep (4 round trips at K = 100 instead of 7) and the NEXT tile's loads are issued before the
-// current tile's FMAs (register staging): 32 / 50 us -> see DESIGN.md section 7.
+// LDS-tiled SGEMM on the matrix cores, 64x64 tile, 32-deep steps (generator's Dense(100 -> 8192) and its weight gradient).
+// Small problem (0.4 GFLOP, K = 100 or the batch): what it waits for is the global -> LDS round trip of every step, so the
+// steps are deep (4 round trips at K = 100 instead of 7) and the NEXT tile's loads are issued before the current tile's
+// products (register staging).  Round 3: the products of a step run on v_mfma_f32_32x32x2_f32 (exact fp32; one 32x32 tile per
+// wave, fragments read k-major from LDS: lanes along m / n are consecutive words, conflict-free) instead of 4x4 FMA blocks per
+// thread: 22 -> see DESIGN.md section 7.
+typedef float gemm_floatx16 __attribute__((ext_vector_type(16)));
 __global__ __launch_bounds__(kT) void gemm_tiled_kernel(const float* __restrict__ A, const float* __restrict__ Bm,
                                                         float* __restrict__ C, int M, int N, int K, int transA, int transB,
                                                         const float* __restrict__ bias, float beta, float scale) {
   constexpr int KT = 32, NL = 64 * KT / kT;                   // 8 elements per thread per operand tile
   __shared__ float As[KT][64 + 4], Bs[KT][64 + 4];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int li = lane & 31, kk = lane >> 5, wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
-  float acc[4][4];
+  gemm_floatx16 acc;
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int q = 0; q < 16; ++q) acc[q] = 0.f;
   float ra[NL], rb[NL];
   auto gload = [&](int k0) {                                  // A tile -> As[k][m]; B tile -> Bs[k][n]; contiguous index fastest
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int e = threadIdx.x + i * kT;
-      int kk, mm;
-      if (transA) { kk = e >> 6; mm = e & 63; } else { mm = e / KT; kk = e - mm * KT; }
-      const int m = m0 + mm, k = k0 + kk;
+      int ka, mm;
+      if (transA) { ka = e >> 6; mm = e & 63; } else { mm = e / KT; ka = e - mm * KT; }
+      const int m = m0 + mm, k = k0 + ka;
       ra[i] = (m < M && k < K) ? (transA ? A[(size_t)k * M + m] : A[(size_t)m * K + k]) : 0.f;
       int kb, nn;
       if (transB) { nn = e / KT; kb = e - nn * KT; } else { kb = e >> 6; nn = e & 63; }
@@ -70,9 +72,9 @@ __global__ __launch_bounds__(kT) void gemm_tiled_kernel(const float* __restrict_
 #pragma unroll
     for (int i = 0; i < NL; ++i) {
       const int e = threadIdx.x + i * kT;
-      int kk, mm;
-      if (transA) { kk = e >> 6; mm = e & 63; } else { mm = e / KT; kk = e - mm * KT; }
-      As[kk][mm] = ra[i];
+      int ka, mm;
+      if (transA) { ka = e >> 6; mm = e & 63; } else { mm = e / KT; ka = e - mm * KT; }
+      As[ka][mm] = ra[i];
       int kb, nn;
       if (transB) { nn = e / KT; kb = e - nn * KT; } else { kb = e >> 6; nn = e & 63; }
       Bs[kb][nn] = rb[i];
@@ -82,31 +84,22 @@ __global__ __launch_bounds__(kT) void gemm_tiled_kernel(const float* __restrict_
   for (int k0 = 0; k0 < K; k0 += KT) {
     lstore();
     __syncthreads();
-    if (k0 + KT < K) gload(k0 + KT);                          // in flight under this tile's FMAs
+    if (k0 + KT < K) gload(k0 + KT);                          // in flight under this tile's products
+    const float* ap = &As[kk][wm * 32 + li];                  // + 2p rows: A[m = li][k = 2p + kk]
+    const float* bp = &Bs[kk][wn * 32 + li];
 #pragma unroll
-    for (int kk = 0; kk < KT; ++kk) {
-      float a[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) a[i] = As[kk][ty * 4 + i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = Bs[kk][tx * 4 + j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
-    }
+    for (int p = 0; p < KT / 2; ++p) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ap[2 * p * 68], bp[2 * p * 68], acc, 0, 0, 0);
     __syncthreads();
   }
+  // acc[q] of lane (li, kk) = C[row (q & 3) + 8 (q >> 2) + 4 kk][col li] of the wave's 32x32 tile
+  const int n = n0 + wn * 32 + li;
+  if (n < N) {
+    const float bn = bias ? bias[n] : 0.f;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + ty * 4 + i;
-    if (m >= M) continue;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + tx * 4 + j;
-      if (n >= N) continue;
-      float v = scale * acc[i][j];
-      if (bias) v += bias[n];
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kk;
+      if (m >= M) continue;
+      float v = scale * acc[q] + bn;
       const size_t e = (size_t)m * N + n;
       if (beta != 0.f) v += beta * C[e];
       C[e] = v;
