@@ -339,11 +339,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
 // every tap; weights come through the scalar cache (wave-uniform addresses).  Pixel stride in LDS is
 // CK+4 floats so the per-lane ds_read_b128 of neighbouring pixels is bank-conflict free.
 // ------------------------------------------------------------------------------------------------
-constexpr int kThinTH = 8, kThinTW = 32;
-
-template <int CK>
+// TW = 32 (8 rows) or 16 (16 rows): phases no wider than 16 anchors (MNIST's ConvT 64 -> 1 on 14 x 14 anchors) take the square
+// tile -- one workgroup per (image, phase) with 77 % of its threads on real pixels instead of two half-empty 8 x 32 tiles
+// (38 %), i.e. one round of workgroups instead of two (round 3: 90 -> see DESIGN.md section 7).
+template <int CK, int kThinTW>
 __global__ __launch_bounds__(256) void conv_thin_n_patch_kernel(const GatherParams p, int tiles_x, int tiles_y) {
   extern __shared__ __attribute__((aligned(16))) float patch[];
+  constexpr int kThinTH = 256 / kThinTW;
   constexpr int CS = CK + 4, Q = CK / 4;
   const int phase = blockIdx.z % p.nphase, b = blockIdx.z / p.nphase;
   const GatherPhase& g = p.ph[phase];
@@ -1027,7 +1029,9 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
   if (p.N <= 4 && (p.Ck == 16 || p.Ck == 32 || p.Ck == 64)) {
     // LDS patch kernel: patch = anchor tile + tap halo of the widest phase
     size_t lds = 0;
-    int tiles_x = 0, tiles_y = 0;
+    int tiles_x = 0, tiles_y = 0, wmax = 0;
+    for (int i = 0; i < p.nphase; ++i) wmax = std::max(wmax, p.ph[i].Wa);
+    const int kThinTW = wmax <= 16 ? 16 : 32, kThinTH = 256 / kThinTW;
     for (int i = 0; i < p.nphase; ++i) {
       int mny = 127, mxy = -127, mnx = 127, mxx = -127;
       for (int t = 0; t < p.ph[i].ntaps; ++t) {
@@ -1042,17 +1046,23 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     if (lds <= 150 * 1024 && (size_t)p.B * p.nphase <= 65535) {
       static bool attr_set = false;
       if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_n_patch_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_n_patch_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_n_patch_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+#define BG_TNP_ATTR(CKv, TWv) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_n_patch_kernel<CKv, TWv>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
+        BG_TNP_ATTR(16, 32); BG_TNP_ATTR(32, 32); BG_TNP_ATTR(64, 32); BG_TNP_ATTR(16, 16); BG_TNP_ATTR(32, 16); BG_TNP_ATTR(64, 16);
+#undef BG_TNP_ATTR
         attr_set = true;
       }
       snprintf(name, sizeof name, "conv_thin_n_patch_%s", tag);
       dim3 grid(tiles_x, tiles_y, p.B * p.nphase);
       bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
-      if (p.Ck == 16) hipLaunchKernelGGL(conv_thin_n_patch_kernel<16>, grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);
-      else if (p.Ck == 32) hipLaunchKernelGGL(conv_thin_n_patch_kernel<32>, grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);
-      else hipLaunchKernelGGL(conv_thin_n_patch_kernel<64>, grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);
+#define BG_TNP(CKv)                                                                                                        \
+  do {                                                                                                                     \
+    if (kThinTW == 16) hipLaunchKernelGGL((conv_thin_n_patch_kernel<CKv, 16>), grid, dim3(256), lds, L.s, p, tiles_x, tiles_y); \
+    else hipLaunchKernelGGL((conv_thin_n_patch_kernel<CKv, 32>), grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);          \
+  } while (0)
+      if (p.Ck == 16) BG_TNP(16);
+      else if (p.Ck == 32) BG_TNP(32);
+      else BG_TNP(64);
+#undef BG_TNP
       return L.done(name);
     }
   }

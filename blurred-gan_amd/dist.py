@@ -93,8 +93,18 @@ def all_reduce_sum_async(flat):
 
 
 def all_reduce_sum_(flat):
-    """In-place SUM all-reduce of a flat buffer (no-op for a single replica)."""
-    all_reduce_sum_async(flat).wait()
+    """In-place SUM all-reduce of a flat buffer, IN LINE on the current stream (no-op for a single replica).  The forward SyncBN
+    exchanges of the G-step have nothing to overlap with, so they skip the collective stream and its two event hops (round 3):
+    the ABI communicator takes the compute stream as its stream argument, and torch's process group runs a synchronous
+    (``async_op=False``) collective on the caller's current stream."""
+    if not collectives_active():
+        return flat
+    if _use_abi_comm(flat):
+        AbiComm.get().all_reduce_inline(flat)
+    elif flat.is_cuda and td.get_backend() != "gloo" and os.environ.get("BGAN_DP_INLINE_SYNC", "1") != "0":
+        td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=False)
+    else:
+        all_reduce_sum_async(flat).wait()
     return flat
 
 
@@ -137,6 +147,12 @@ class AbiComm:
         done = torch.cuda.Event()
         done.record(self.stream)
         return _AbiWork(done)
+
+    def all_reduce_inline(self, seg):
+        """In-place SUM of ``seg`` as the next operation of the CURRENT stream (RCCL orders it against this communicator's
+        collectives on the private stream by itself)."""
+        self._check(self._lib.bg_allreduce_sum_f32(self._h, seg.data_ptr(), seg.numel(), torch.cuda.current_stream().cuda_stream),
+                    "bg_allreduce_sum_f32")
 
     def close(self):
         if self._h:
