@@ -9,7 +9,7 @@
 //   * data gradient of a stride-s conv: exactly this with the kernel array as it lies in memory ([tap][ci][co]);
 //   * stride-1 forward conv: the same with the taps flipped (kh -> k-1-kh, kw -> k-1-kw) and the pads mirrored.
 // A wave owns 16 pixels of the row; the input row is read once (coalesced float4 -> LDS -> A fragments of
-// v_mfma_f32_16x16x4_f32, loads two rows ahead), the k*Ck/4 weight fragments stay in registers for the whole kernel, and the k
+// v_mfma_f32_16x16x4_f32, four rows in flight), the k*Ck/4 weight fragments stay in registers for the whole kernel, and the k
 // output rows in flight live in k accumulators that shift down by s places after every input row.
 // A finished row goes through LDS once for the kw shift-add and leaves as contiguous stores with the fused epilogue.
 // MFMA-bound (no padding of the thin dimension beyond 15 -> 16 columns): 2 * rows * W * Ck * k * 16 flop.
@@ -41,13 +41,30 @@ struct RowParams {
 
 __device__ inline int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); }
 
-template <int KS, int K, int S, int PIXW>     // Ck = 4*KS, K x K taps, stride S of the scatter, PIXW input pixels per workgroup
+// tanh without a branch (the library's tanhf has two, and a branch ends the basic block the row loop wants to be): the exponential
+// form  sign(x) (1 - 2 / (e^(2|x|) + 1))  (absolute error ~ 2e-7, the hardware exp2 and reciprocal), and below |x| = 0.1, where
+// that form loses RELATIVE accuracy, the odd series through x^7 (next term 2e-11).  Selected, not branched.
+__device__ inline float tanh_branchless(float x) {
+  const float ax = fminf(fabsf(x), 15.f);
+  const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);          // e^(2 ax)
+  const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
+  const float x2 = ax * ax;
+  const float small = ax * fmaf(x2, fmaf(x2, fmaf(x2, -17.f / 315.f, 2.f / 15.f), -1.f / 3.f), 1.f);
+  return copysignf(ax < 0.1f ? small : big, x);
+}
+
+// Ck = 4*KS, K x K taps, stride S of the scatter, PIXW input pixels per workgroup, EP: epilogue as a compile-time constant for the
+// two cases the networks use -- 0 = bias only (data gradients), 1 = bias + tanh (the generator's last conv) -- so that the row
+// loop is ONE basic block the scheduler can interleave; 2 = any epilogue (uniform branches, per-element loads)
+template <int KS, int K, int S, int PIXW, int EP>
 __global__ __launch_bounds__(PIXW * 4) void conv_rows_scatter_kernel(const RowParams p) {
   constexpr int NTH = PIXW * 4;                              // one wave per 16 input pixels
+  constexpr unsigned kOob = 0x80000000u;
   extern __shared__ __attribute__((aligned(16))) float row_lds[];
   constexpr int AS = 4 * KS + 4;                             // A row stride in LDS: conflict-free b32 fragment reads, 16-B aligned rows
   float* abuf = row_lds;                                     // [2][ipw * Wi][AS]   input rows r, r+1
-  float* pbuf = row_lds + 2 * PIXW * AS;                     // [2][S][ipw * Wi][17] finished P tiles (ipw * Wi = PIXW pixels)
+  constexpr int PS = PIXW * 17 + 1;                          // one P slot: PIXW pixels x 17 floats + ONE ZERO the absent kw terms read
+  float* pbuf = row_lds + 2 * PIXW * AS;                     // [2][S][PS] finished P tiles (ipw * Wi = PIXW pixels)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, kq = lane >> 4;
   const int t = wave % p.wpr, img = wave / p.wpr;
@@ -57,53 +74,74 @@ __global__ __launch_bounds__(PIXW * 4) void conv_rows_scatter_kernel(const RowPa
   const int iy_lo = -floordiv(-(y0 + p.pt - (K - 1)), S);          // ceil((y0 + pt - (K-1)) / S)
   const int iy_hi = floordiv(y1 - 1 + p.pt, S);
   const int nrows = iy_hi - iy_lo + 1;
+  // The workgroup's images as two buffers: a row that does not exist, an image past the batch or an output element nobody owns is
+  // an out-of-range OFFSET (loads return 0, stores are dropped), so the row loop has no branch around a memory instruction and the
+  // compiler's wait counts are exact -- with the loads behind `if`s it waited for the rows it had just requested (vmcnt(0) in front
+  // of the MFMAs) and the kernel ran at the SUM of its matrix time and its memory latency (round 3: 87 = 47 + 39 us on the
+  // generator's last conv at batch 256).
+  const int nimg = min(p.ipw, p.B - bgrp * p.ipw);
+  const size_t img0 = (size_t)bgrp * p.ipw;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A + img0 * p.Hi * p.Wi * Ck), 0,
+                                                                        nimg * p.Hi * p.Wi * Ck * 4, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(p.C + img0 * p.Ho * p.Wo * N, 0, nimg * p.Ho * p.Wo * N * 4, 0x00020000);
 
   // weight fragments B[k = c][j = kw*N + n], all K kernel rows, resident
   float bw[K][KS];
   {
-    const int kw = li / N, n = li - kw * N;
+    const int lc = min(li, K * N - 1);
+    const int kw = lc / N, n = lc - kw * N;
 #pragma unroll
     for (int kh = 0; kh < K; ++kh) {
       const int tap = p.flip ? (K - 1 - kh) * K + (K - 1 - kw) : kh * K + kw;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) bw[kh][ks] = li < K * N ? p.Wt[((size_t)tap * N + n) * Ck + 4 * ks + kq] : 0.f;
+      for (int ks = 0; ks < KS; ++ks) {
+        const float w = p.Wt[((size_t)tap * N + n) * Ck + 4 * ks + kq];
+        bw[kh][ks] = li < K * N ? w : 0.f;
+      }
     }
   }
   floatx4 acc[K];
 #pragma unroll
   for (int i = 0; i < K; ++i) acc[i] = floatx4{0.f, 0.f, 0.f, 0.f};
 
-  // Input rows travel global -> registers (coalesced float4, two rows ahead) -> LDS -> A fragments; a direct gather of the
-  // fragment layout from global (16 cache lines per wave instruction) cost as much as all the MFMAs.
+  // Input rows travel global -> registers (coalesced float4) -> LDS -> A fragments; a direct gather of the fragment layout from
+  // global (16 cache lines per wave instruction) cost as much as all the MFMAs.  Everything of a row load that does not depend on
+  // the row is worked out once.
   constexpr int QPR = KS;                                    // float4 per pixel
   constexpr int NQ = PIXW * QPR / NTH;                       // float4 per thread per row set (PIXW pixels x Ck)
   static_assert(NQ >= 1, "Ck >= 16");
+  unsigned g_off[NQ], l_off[NQ];                             // byte offset of (image, row 0, ix, 4 c4) in the workgroup's images
+#pragma unroll
+  for (int q = 0; q < NQ; ++q) {
+    const int f = tid + q * NTH, pix = f / QPR, c4 = f - pix * QPR;          // pix = im * Wi + ix
+    const int im = pix / p.Wi, ix = pix - im * p.Wi;
+    g_off[q] = im < nimg ? (unsigned)(((im * p.Hi * p.Wi + ix) * Ck + c4 * 4) * 4) : kOob;
+    l_off[q] = (unsigned)(pix * AS + c4 * 4);
+  }
+  const int rowB = p.Wi * Ck * 4;
   auto gload = [&](int r, float4 (&g)[NQ]) {
     const int iy = iy_lo + r;
+    const bool row_ok = r < nrows && (unsigned)iy < (unsigned)p.Hi;          // wave-uniform
+    const unsigned add = row_ok ? (unsigned)(iy * rowB) : 0u, force = row_ok ? 0u : kOob;
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int f = tid + q * NTH, pix = f / QPR, c4 = f - pix * QPR;        // pix = im * Wi + ix
-      const int im = pix / p.Wi, ix = pix - im * p.Wi;
-      const int bb = bgrp * p.ipw + im;
-      const bool ok = bb < p.B && r < nrows && (unsigned)iy < (unsigned)p.Hi;
-      g[q] = ok ? *reinterpret_cast<const float4*>(p.A + (((size_t)bb * p.Hi + iy) * p.Wi + ix) * Ck + c4 * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
+    for (int q = 0; q < NQ; ++q)
+      g[q] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, (g_off[q] + add) | force, 0, 0));
   };
   auto lstore = [&](int buf, const float4 (&g)[NQ]) {
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) {
-      const int f = tid + q * NTH, pix = f / QPR, c4 = f - pix * QPR;
-      *reinterpret_cast<float4*>(abuf + (size_t)buf * PIXW * AS + pix * AS + c4 * 4) = g[q];
-    }
+    for (int q = 0; q < NQ; ++q) *reinterpret_cast<float4*>(abuf + (size_t)buf * PIXW * AS + l_off[q]) = g[q];
   };
   const float* afrag = abuf + ((size_t)img * p.Wi + 16 * t + li) * AS + kq;
   // Row-independent part of the kw shift-add, per thread: output element e = (image, x, n) of a finished row sums the
-  // P columns (kw, n) of the input pixels ix = (x + pl - kw) / S that exist.  Offsets into one P buffer, -1 = no term.
+  // P columns (kw, n) of the input pixels ix = (x + pl - kw) / S that exist.  Offsets into one P buffer; a term that does not
+  // exist reads the slot's zero.
   constexpr int NE = 3;                                      // output elements per thread: ipw * Wo * N <= 3 * NTH (host-checked)
   constexpr int NTERM = (K + S - 1) / S;
   int e_src[NE][NTERM];
-  long e_dst[NE];                                            // offset of (image, y = 0, x, n) in the output, -1 = none
+  unsigned e_dst[NE];                                        // byte offset of (image, y = 0, x, n) in the workgroup's output, kOob = none
+  float e_bias[NE], e_mul[NE];                               // the epilogue's per-channel operands
   int e_n[NE];
+  if (tid < 2 * S) pbuf[(size_t)tid * PS + PIXW * 17] = 0.f; // visible after the first barrier below
   {
     const int per_img = p.Wo * N;
 #pragma unroll
@@ -111,79 +149,135 @@ __global__ __launch_bounds__(PIXW * 4) void conv_rows_scatter_kernel(const RowPa
       const int e = tid + q * NTH;
       const int im = e / per_img, rem = e - im * per_img;
       const int x = rem / N, n = rem - x * N;
-      const int bb = bgrp * p.ipw + im;
-      const bool ok = e < p.ipw * per_img && bb < p.B;
-      e_dst[q] = ok ? ((long)bb * p.Ho * p.Wo + x) * N + n : -1;
+      const bool ok = e < p.ipw * per_img && im < nimg;
+      e_dst[q] = ok ? (unsigned)(((im * p.Ho * p.Wo + x) * N + n) * 4) : kOob;
       e_n[q] = n;
+      e_bias[q] = ok && p.bias ? p.bias[n] : 0.f;
+      e_mul[q] = ok && p.epi_mode == BG_EPI_AFFINE_LRELU ? p.ref[n] : 0.f;
 #pragma unroll
       for (int i = 0; i < NTERM; ++i) {
         const int kw = (x + p.pl) % S + i * S;
         const int num = x + p.pl - kw, ix = num / S;
-        e_src[q][i] = (ok && kw < K && num >= 0 && ix < p.Wi) ? (im * p.Wi + ix) * 17 + kw * N + n : -1;
+        e_src[q][i] = (ok && kw < K && num >= 0 && ix < p.Wi) ? (im * p.Wi + ix) * 17 + kw * N + n : PIXW * 17;
       }
     }
   }
+  const size_t out0 = img0 * p.Ho * p.Wo * N;               // element index of the workgroup's first output (EP = 1: ref / keep lookups)
   // finished output row y: P tile -> LDS (before the row's barrier), then kw shift-add, epilogue, contiguous stores (after it)
   auto pwrite = [&](const floatx4& pacc, int slot) {
-    float* pb = pbuf + (size_t)slot * PIXW * 17;
+    float* pb = pbuf + (size_t)slot * PS;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) pb[((size_t)img * p.Wi + 16 * t + 4 * kq + rr) * 17 + li] = pacc[rr];
   };
-  auto pstore = [&](int slot, int y) {
-    const float* pb = pbuf + (size_t)slot * PIXW * 17;
+  auto pstore = [&](int slot, int y, bool live) {            // live (wave-uniform): the row belongs to this strip
+    const float* pb = pbuf + (size_t)slot * PS;
+    float v[NE];
+#pragma unroll
+    for (int q = 0; q < NE; ++q) {                            // all the reads first: one wait for the lot
+      v[q] = pb[e_src[q][0]];
+#pragma unroll
+      for (int i = 1; i < NTERM; ++i) v[q] += pb[e_src[q][i]];
+    }
+    const unsigned add = live ? (unsigned)(y * p.Wo * N * 4) : 0u, force = live ? 0u : kOob;
 #pragma unroll
     for (int q = 0; q < NE; ++q) {
-      if (e_dst[q] < 0) continue;
-      float v = 0.f;
-#pragma unroll
-      for (int i = 0; i < NTERM; ++i)
-        if (e_src[q][i] >= 0) v += pb[e_src[q][i]];
-      const size_t idx = (size_t)(e_dst[q] + (long)y * p.Wo * N);
-      p.C[idx] = bg::apply_epilogue(p, v, idx, e_n[q]);
+      const unsigned off = (e_dst[q] + add) | force;
+      float o;
+      if (EP == 0) {
+        o = v[q] + e_bias[q];
+      } else if (EP == 1) {
+        o = tanh_branchless(v[q] + e_bias[q]);
+      } else {
+        const bool mine = (off & kOob) == 0;                 // the generic epilogue reads ref / keep at the element's index
+        o = mine ? bg::apply_epilogue_pre(p, v[q], out0 + (off >> 2), e_bias[q], e_mul[q]) : 0.f;
+      }
+      __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, o), rsC, off, 0, 0);
     }
   };
 
-  // One input row per trip, one barrier per trip.  acc[kh] always belongs to output row iy*S + kh - pt of the CURRENT input
-  // row: after the row the S finished accumulators are flushed and the rest move down S places (a handful of register moves
-  // against K*KS MFMAs), which keeps the loop body small enough for the instruction cache.
-  //   trip r:  A fragments of row r <- LDS | row r+1 registers -> LDS, loads of row r+2 | MFMAs | P tiles -> LDS | barrier | stores
-  float4 g0[NQ], g1[NQ];
+  // One input row per trip, one barrier per trip (at its top).  acc[kh] always belongs to output row iy*S + kh - pt of the CURRENT
+  // input row: after the row the S finished accumulators go to LDS as P tiles and the rest move down S places.
+  //   trip r:  barrier | A fragments of row r <- LDS | MFMAs of row r, and UNDER them: shift-add + epilogue + stores of row r-1's
+  //            P tiles, row r+1 registers -> LDS, loads of row r+5 | P tiles of row r -> LDS | accumulators move down
+  // Round 3: the kernel used to run [MFMAs] [P tiles] [barrier] [stores] one after the other in every wave, and its time was the
+  // SUM of its matrix time and everything else (87 = 47 + 39 us on the generator's last conv at batch 256, whatever the number of
+  // waves per SIMD): the waves of a workgroup sit on four SIMDs and meet at the barrier every trip, so a wave's latency chain
+  // behind the barrier is idle matrix time on all four.  Now that chain belongs to the PREVIOUS row and sits inside the MFMA block
+  // of the same wave (one basic block: no branch, every load and store unconditional with out-of-range offsets).
+  // Row k travels in register set k % 4 (four rows in flight), LDS row buffers and P slots alternate by parity: unrolled by four.
+  float4 g0[NQ], g1[NQ], g2[NQ], g3[NQ];
   gload(0, g0);
   gload(1, g1);
+  gload(2, g2);
+  gload(3, g3);
   lstore(0, g0);
-  __syncthreads();
-  for (int r = 0; r < nrows; ++r) {
-    const int iy = iy_lo + r, cur = r & 1;
+  gload(4, g0);
+  // Dropped (out-of-range) stores that only exist for the compiler's wait counting: it sizes the vmcnt of a trip's wait by the
+  // SHORTEST path that reaches it, which is this prologue (few instructions after a row's loads), and would make every trip wait
+  // for the loads of the trip before.  With as many stores here as four trips issue, the loop's waits leave the younger rows alone.
+#pragma unroll
+  for (int i = 0; i < 4 * NE * S; ++i) __builtin_amdgcn_raw_buffer_store_b32(0u, rsC, kOob + 4u * i, 0, 0);
+  int y_prev = 0;                                            // output row of slot 0 of the previous trip (rows y_prev .. y_prev + S - 1)
+  bool have_prev = false;
+  auto flush_prev = [&](int prev_par) {                      // shift-add, epilogue and stores of the previous trip's P tiles
+#pragma unroll
+    for (int kh = 0; kh < S; ++kh) {
+      const int y = y_prev + kh;
+      pstore(prev_par * S + kh, y, have_prev & (y >= y0) & (y < y1));    // & not &&: no branch in the row loop
+    }
+  };
+  auto trip = [&](int r, auto parity, float4 (&g)[NQ]) {    // g: row r+1 on entry, row r+5 in flight on exit
+    constexpr int cur = decltype(parity)::value;
+    __syncthreads();
     float a[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) a[ks] = afrag[(size_t)cur * PIXW * AS + 4 * ks];
-    // registers alternate by row parity; the branch is uniform
-    if (cur == 0) { lstore(1, g1); gload(r + 2, g0); } else { lstore(0, g0); gload(r + 2, g1); }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)                          // kh innermost: K independent accumulator chains
 #pragma unroll
       for (int kh = 0; kh < K; ++kh) acc[kh] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[ks], bw[kh][ks], acc[kh], 0, 0, 0);
-    bool fl[S];
+    flush_prev(cur ^ 1);
+    lstore(cur ^ 1, g);
+    gload(r + 5, g);
 #pragma unroll
-    for (int kh = 0; kh < S; ++kh) {                         // rows that just received their last contribution
-      const int y = iy * S + kh - p.pt;
-      fl[kh] = y >= y0 && y < y1;
-      if (fl[kh]) pwrite(acc[kh], cur * S + kh);
-    }
-    __syncthreads();
-#pragma unroll
-    for (int kh = 0; kh < S; ++kh)
-      if (fl[kh]) pstore(cur * S + kh, iy * S + kh - p.pt);
+    for (int kh = 0; kh < S; ++kh) pwrite(acc[kh], cur * S + kh);   // rows that just received their last contribution
+    y_prev = (iy_lo + r) * S - p.pt;
+    have_prev = true;
 #pragma unroll
     for (int i = 0; i < K; ++i) acc[i] = i + S < K ? acc[i + S] : floatx4{0.f, 0.f, 0.f, 0.f};
+  };
+  // whole groups of four trips in the loop (one path through it: exact wait counts), the last one to three after it
+  int r = 0;
+  for (; r + 4 <= nrows; r += 4) {
+    trip(r, std::integral_constant<int, 0>{}, g1);
+    trip(r + 1, std::integral_constant<int, 1>{}, g2);
+    trip(r + 2, std::integral_constant<int, 0>{}, g3);
+    trip(r + 3, std::integral_constant<int, 1>{}, g0);
   }
+  int last_par = 1;                                          // parity of the last trip that ran (nrows >= 1)
+  if (r < nrows) {
+    trip(r, std::integral_constant<int, 0>{}, g1);
+    last_par = 0;
+    if (r + 1 < nrows) {
+      trip(r + 1, std::integral_constant<int, 1>{}, g2);
+      last_par = 1;
+      if (r + 2 < nrows) {
+        trip(r + 2, std::integral_constant<int, 0>{}, g3);
+        last_par = 0;
+      }
+    }
+  }
+  __syncthreads();
+  if (last_par == 0) flush_prev(0); else flush_prev(1);
 }
 
 template <int K, int S>
 int launch_rows(const RowParams& p, dim3 grid, size_t lds, hipStream_t s) {
   const bool wide = p.Wi == 128;
-#define BG_RS(KSv) do { if (wide) hipLaunchKernelGGL((conv_rows_scatter_kernel<KSv, K, S, 128>), grid, dim3(512), lds, s, p); \
-                        else hipLaunchKernelGGL((conv_rows_scatter_kernel<KSv, K, S, 64>), grid, dim3(256), lds, s, p); } while (0)
+  const int ep = p.epi_mode == BG_EPI_NONE ? 0 : p.epi_mode == BG_EPI_TANH ? 1 : 2;
+#define BG_RS2(KSv, EPv) do { if (wide) hipLaunchKernelGGL((conv_rows_scatter_kernel<KSv, K, S, 128, EPv>), grid, dim3(512), lds, s, p); \
+                              else hipLaunchKernelGGL((conv_rows_scatter_kernel<KSv, K, S, 64, EPv>), grid, dim3(256), lds, s, p); } while (0)
+#define BG_RS(KSv) do { if (ep == 0) BG_RS2(KSv, 0); else if (ep == 1) BG_RS2(KSv, 1); else BG_RS2(KSv, 2); } while (0)
   switch (p.Ck) {
     case 16: BG_RS(4); return 1;
     case 32: BG_RS(8); return 1;
@@ -191,6 +285,7 @@ int launch_rows(const RowParams& p, dim3 grid, size_t lds, hipStream_t s) {
     default: return 0;
   }
 #undef BG_RS
+#undef BG_RS2
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -405,6 +500,7 @@ int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B,
   p.ipw = p.Wi == 128 ? 1 : 4 / p.wpr;
   const int pixw = p.Wi == 128 ? 128 : 64;
   if ((long)p.ipw * p.Wo * p.N > 3L * pixw * 4) return BG_OK;                          // output elements per thread of the shift-add
+  if ((size_t)p.ipw * p.Hi * p.Wi * p.Ck >= (1ull << 29) || (size_t)p.ipw * p.Ho * p.Wo * p.N >= (1ull << 29)) return BG_OK;   // a workgroup's images are one buffer: 31-bit byte offsets
   p.epi_mode = BG_EPI_NONE; p.alpha = 0.3f; p.scale = 1.f;
   if (epi) {
     BG_REQUIRE(epi->mode >= BG_EPI_NONE && epi->mode <= BG_EPI_AFFINE_LRELU, BG_ERR_UNSUPPORTED, "conv rows: epilogue mode %d", epi->mode);
@@ -413,7 +509,7 @@ int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B,
     p.epi_mode = epi->mode; p.bias = epi->bias; p.ref = epi->ref; p.keep = epi->keep; p.keep_elems = epi->keep_elems; p.alpha = epi->alpha; p.scale = epi->scale;
   }
   const dim3 grid((unsigned)(cdiv(B, p.ipw) * p.strips));
-  const size_t lds = ((size_t)2 * pixw * (p.Ck + 4) + (size_t)2 * s * pixw * 17) * sizeof(float);
+  const size_t lds = ((size_t)2 * pixw * (p.Ck + 4) + (size_t)2 * s * (pixw * 17 + 1)) * sizeof(float);
   const double flops = 2.0 * B * (double)H * W * Cin * Cout * k * k / (s * s);
   Launch L(stream, bwd_data ? "conv_rows_dgrad" : "conv_rows_fwd", flops, 0);
   int ok;
