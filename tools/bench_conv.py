@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--only", default="")
+    ap.add_argument("--epi", action="store_true", help="the step's epilogues: bias + LeakyReLU + dropout mask (forward), LeakyReLU gradient x mask (data gradient)")
     a = ap.parse_args()
     B = a.batch
     torch.manual_seed(0)
@@ -68,6 +69,13 @@ def main():
         nf, nd = ops.conv2d_splitk_workspace_bytes(False, B, H, W, Ci, Co, 5, s), ops.conv2d_splitk_workspace_bytes(True, B, H, W, Ci, Co, 5, s)
         wsk = torch.empty(max(nf, nd) // 4 + 4, device="cuda")
         ef, ed = ops.epilogue(ws=wsk if nf else None), ops.epilogue(ws=wsk if nd else None)     # split-K scratch as the engine passes it
+        if a.epi:
+            bias = torch.rand(Co, device="cuda") - 0.5
+            keep_y = (torch.rand(dy.shape, device="cuda") < 0.7).to(torch.uint8)
+            keep_x = (torch.rand(x.shape, device="cuda") < 0.7).to(torch.uint8)
+            ref_x = torch.rand(x.shape, device="cuda") - 0.5
+            ef = ops.epilogue(ops.EPI_BIAS_LRELU, bias=bias, keep=keep_y, scale=1 / 0.7, ws=wsk if nf else None)
+            ed = ops.epilogue(ops.EPI_MUL_GRAD, ref=ref_x, keep=keep_x, scale=1 / 0.7, ws=wsk if nd else None)
         for op, fn in (("fwd", lambda: ops.conv2d_fwd(x, wT, y, 5, s, ef)), ("dgrad", lambda: ops.conv2d_bwd_data(dy, w, dx, 5, s, ed)),
                        ("wgrad", lambda: ops.conv2d_bwd_filter(x, dy, dw, 5, s, 0.0, 1.0, ws))):
             ms, fl, names = run(fn, a.iters)
