@@ -145,6 +145,22 @@ __global__ __launch_bounds__(256) void conv_c16_dgrad_kernel(const C16Params p) 
       // pixel write its 64 bytes, and the two px phases are neighbouring pixels
       {
         const size_t rowbase = ((size_t)b * p.Hd + 2 * a + py) * p.Wd;
+        // critic data gradient: the reference values and mask bytes of ALL the lane's outputs are requested before the first is
+        // used (unconditional loads: a mask that does not cover an element is read at element 0 and ignored).  One (mt, px) at a
+        // time -- load, wait, load, wait, store -- cost the 16 -> 32 layer of the 128-pixel critic +63 % at 3 x 128 samples.
+        float4 e_ref[MT][2];
+        uchar4 e_keep[MT][2];
+        if (epi_kind == 1) {
+          const uint8_t* kptr = p.keep ? p.keep : reinterpret_cast<const uint8_t*>(p.ref);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+              const size_t idx = (rowbase + 2 * (mh * (WS / 2) + mt * 16 + li) + px) * 16 + 4 * kq;
+              e_ref[mt][px] = *reinterpret_cast<const float4*>(p.ref + idx);
+              e_keep[mt][px] = *reinterpret_cast<const uchar4*>(kptr + ((p.keep_elems == 0 || idx < p.keep_elems) ? idx : 0));
+            }
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
           const int c = mh * (WS / 2) + mt * 16 + li;
@@ -156,10 +172,10 @@ __global__ __launch_bounds__(256) void conv_c16_dgrad_kernel(const C16Params p) 
             if (epi_kind == 0) {                               // no epilogue (ConvT -> BatchNorm): straight-line stores
               o = make_float4(v[0], v[1], v[2], v[3]);
             } else if (epi_kind == 1) {                        // critic data gradient: LeakyReLU' of the layer input, dropout mask
-              const float4 r = *reinterpret_cast<const float4*>(p.ref + idx);
+              const float4 r = e_ref[mt][px];
               float f0 = r.x > 0.f ? 1.f : p.alpha, f1 = r.y > 0.f ? 1.f : p.alpha, f2 = r.z > 0.f ? 1.f : p.alpha, f3 = r.w > 0.f ? 1.f : p.alpha;
               if (p.keep && (p.keep_elems == 0 || idx < p.keep_elems)) {
-                const uchar4 k4 = *reinterpret_cast<const uchar4*>(p.keep + idx);
+                const uchar4 k4 = e_keep[mt][px];
                 f0 = k4.x ? f0 * p.scale : 0.f; f1 = k4.y ? f1 * p.scale : 0.f; f2 = k4.z ? f2 * p.scale : 0.f; f3 = k4.w ? f3 * p.scale : 0.f;
               }
               o = make_float4((v[0] + e_bias[0]) * f0, (v[1] + e_bias[1]) * f1, (v[2] + e_bias[2]) * f2, (v[3] + e_bias[3]) * f3);
@@ -267,6 +283,14 @@ __global__ __launch_bounds__(256) void conv_c16_fwd_kernel(const C16Params p) {
       }
     // reg rr of lane (li, kq) = out[pixel 16*mt + li][channel 16*nt + 4*kq + rr]
     const size_t rowbase = ((size_t)b * p.Hd + oy) * WO;
+    uchar4 e_keep[MT];                                         // critic forward: all the mask bytes requested before the first is used
+    if (epi_kind == 1 && p.keep) {
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const size_t idx = (rowbase + mt * 16 + li) * 32 + nt * 16 + 4 * kq;
+        e_keep[mt] = *reinterpret_cast<const uchar4*>(p.keep + ((p.keep_elems == 0 || idx < p.keep_elems) ? idx : 0));
+      }
+    }
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
       const size_t idx = (rowbase + mt * 16 + li) * 32 + nt * 16 + 4 * kq;
@@ -278,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_c16_fwd_kernel(const C16Params p) {
         float t0 = v[0] + e_bias[0], t1 = v[1] + e_bias[1], t2 = v[2] + e_bias[2], t3 = v[3] + e_bias[3];
         t0 = t0 > 0.f ? t0 : p.alpha * t0; t1 = t1 > 0.f ? t1 : p.alpha * t1; t2 = t2 > 0.f ? t2 : p.alpha * t2; t3 = t3 > 0.f ? t3 : p.alpha * t3;
         if (p.keep && (p.keep_elems == 0 || idx < p.keep_elems)) {
-          const uchar4 k4 = *reinterpret_cast<const uchar4*>(p.keep + idx);
+          const uchar4 k4 = e_keep[mt];
           t0 = k4.x ? t0 * p.scale : 0.f; t1 = k4.y ? t1 * p.scale : 0.f; t2 = k4.z ? t2 * p.scale : 0.f; t3 = k4.w ? t3 * p.scale : 0.f;
         }
         o = make_float4(t0, t1, t2, t3);
