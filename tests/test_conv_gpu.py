@@ -167,6 +167,54 @@ def test_c16_epilogues():
     np.testing.assert_allclose(yt.cpu().numpy(), np.tanh(z), rtol=1e-4, atol=tolf)
 
 
+@pytest.mark.parametrize("B,HW", [(5, 16), (3, 32), (2, 64)])
+def test_thin_n_row_kernel_epilogues(B, HW):
+    """conv_rows_scatter_kernel (<= 3 channels out): its three epilogue variants -- bias only, bias + tanh (branch-free tanh), and
+    the generic one with per-element loads -- on workgroups that hold 4 / 2 / 1 images (B = 5 at 16 pixels leaves a group with one
+    image: the rest of its buffer is out of range), forward and data gradient, masks on the leading samples only."""
+    from blurred_gan_amd import ops
+    from blurred_gan_amd._lib import EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_NONE, EPI_AFFINE_LRELU
+    rng = np.random.default_rng(100 + HW)
+    # forward 32 -> 3, stride 1
+    Ci, Co, s = 32, 3, 1
+    x, w, _ = _data(B, HW, HW, Ci, Co, s, seed=HW)
+    bias = rng.normal(size=Co)
+    z = O.conv2d_fwd(x, w, s) + bias
+    wT = dev(np.transpose(w, (0, 1, 3, 2)))
+    out = lambda: torch.empty(z.shape, device="cuda")
+    tol = conv_tol(25 * Ci, np.abs(z).max())
+    y = ops.conv2d_fwd(dev(x), wT, out(), 5, s, ops.epilogue(EPI_NONE, bias=dev(bias)))
+    np.testing.assert_allclose(y.cpu().numpy(), z, rtol=1e-4, atol=tol)
+    y = ops.conv2d_fwd(dev(x), wT, out(), 5, s, ops.epilogue(EPI_TANH, bias=dev(bias)))
+    np.testing.assert_allclose(y.cpu().numpy(), np.tanh(z), rtol=1e-4, atol=tol)
+    keep = (rng.uniform(size=z.shape) >= 0.3).astype(np.uint8)
+    nk = (B - 1) * z[0].size                                    # the mask covers all samples but the last
+    y = ops.conv2d_fwd(dev(x), wT, out(), 5, s, ops.epilogue(EPI_BIAS_LRELU, bias=dev(bias), keep=dev(keep, torch.uint8), alpha=0.3,
+                                                              scale=1 / 0.7, keep_elems=nk))
+    exp = O.lrelu_fwd(z)
+    exp[:B - 1] = exp[:B - 1] * keep[:B - 1] / 0.7
+    np.testing.assert_allclose(y.cpu().numpy(), exp, rtol=1e-4, atol=2 * tol)
+    mul = rng.uniform(0.5, 1.5, size=Co)
+    z0 = O.conv2d_fwd(x, w, s)
+    y = ops.conv2d_fwd(dev(x), wT, out(), 5, s, ops.epilogue(EPI_AFFINE_LRELU, bias=dev(bias), ref=dev(mul), alpha=0.3))
+    np.testing.assert_allclose(y.cpu().numpy(), O.lrelu_fwd(z0 * mul + bias), rtol=1e-4, atol=2 * tol)
+    # data gradient of a stride-2 conv 3 -> 32 (dy has 32 channels, dx 3): LeakyReLU' x mask of the layer input, and plain
+    Ci, Co, s = 3, 32, 2
+    x, w, dy = _data(B, 2 * HW, 2 * HW, Ci, Co, s, seed=HW + 1)
+    dxr = O.conv2d_bwd_data(dy, w, s, (2 * HW, 2 * HW))
+    told = conv_tol(25 * Co, np.abs(dxr).max())
+    dx = ops.conv2d_bwd_data(dev(dy), dev(w), torch.empty(x.shape, device="cuda"), 5, s, None)
+    np.testing.assert_allclose(dx.cpu().numpy(), dxr, rtol=1e-4, atol=told)
+    ref_act = rng.normal(size=x.shape)
+    keep_x = (rng.uniform(size=x.shape) >= 0.3).astype(np.uint8)
+    dx = ops.conv2d_bwd_data(dev(dy), dev(w), torch.empty(x.shape, device="cuda"), 5, s,
+                             ops.epilogue(EPI_MUL_GRAD, ref=dev(ref_act), keep=dev(keep_x, torch.uint8), alpha=0.3, scale=1 / 0.7,
+                                          keep_elems=(B - 1) * x[0].size))
+    expd = dxr * O.lrelu_mask(ref_act)
+    expd[:B - 1] *= keep_x[:B - 1] / 0.7
+    np.testing.assert_allclose(dx.cpu().numpy(), expd, rtol=1e-4, atol=2 * told)
+
+
 def test_conv_transpose_roles():
     """Conv2DTranspose forward = bwd_data with the kernel array as is; its filter gradient swaps x and dy."""
     from blurred_gan_amd import ops
