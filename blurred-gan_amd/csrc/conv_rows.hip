@@ -315,7 +315,9 @@ struct RowGParams {
   float alpha, scale;
 };
 
-template <int TG, int NT, int K>     // TG pixel tiles per unit, N = 16 * NT, K x K taps
+// TG pixel tiles per unit, N = 16 * NT, K x K taps, MASK: the bias + LeakyReLU + dropout-mask epilogue of the critic's first layer
+// as a variant of its own (its batched mask loads cost registers the other epilogues' variant should not pay: a wave per SIMD)
+template <int TG, int NT, int K, bool MASK>
 __global__ __launch_bounds__(256) void conv_rows_gather_kernel(const RowGParams p) {
   extern __shared__ __attribute__((aligned(16))) float xl[];       // [(R-1)*s + K][Wi*Ct + 2*halo]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -393,26 +395,50 @@ __global__ __launch_bounds__(256) void conv_rows_gather_kernel(const RowGParams 
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt) acc[tg][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[tg][ks], bw[kh][ks][nt], acc[tg][nt], 0, 0, 0);
     }
+    // critic forward (bias + LeakyReLU + dropout): the mask bytes of one pixel tile (4 x NT per lane) are requested together, with
+    // unconditional loads (an element the mask does not cover reads byte 0 and ignores it).  Inside the per-element epilogue each was
+    // a load and a wait of its own -- 16 memory latencies in a row per unit, +30 % on the first critic layer at 3 x 128 samples
+    // (round 3).  Tile by tile, not the whole unit at once: the unit's 16 x NT bytes cost the wide variants a wave per SIMD.
+    constexpr bool mask_epi = MASK;                           // host: p.epi_mode == BG_EPI_BIAS_LRELU && p.keep
     // reg rr of lane l = out[ox = ox0 + 16*tg + 4*kq + rr][n = 16*nt + li]  (64-B pieces per store; a transpose through LDS to
     // float4 stores measured no faster -- the kernel is bound by its short per-strip life, not by the stores)
 #pragma unroll
-    for (int tg = 0; tg < TG; ++tg)
+    for (int tg = 0; tg < TG; ++tg) {
+      const size_t pix0 = ((size_t)b * p.Ho + oy) * p.Wo + ox0 + 16 * tg + 4 * kq;
+      unsigned char e_keep[4][NT];
+      if (mask_epi) {
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const size_t pix = ((size_t)b * p.Ho + oy) * p.Wo + ox0 + 16 * tg + 4 * kq + rr;
+        for (int rr = 0; rr < 4; ++rr)
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt) {
+            const size_t idx = (pix0 + rr) * N + nt * 16 + li;
+            e_keep[rr][nt] = p.keep[(p.keep_elems == 0 || idx < p.keep_elems) ? idx : 0];
+          }
+      }
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
-          const size_t idx = pix * N + nt * 16 + li;
-          p.C[idx] = bg::apply_epilogue_pre(p, acc[tg][nt][rr], idx, e_bias[nt], e_mul[nt]);
+          const size_t idx = (pix0 + rr) * N + nt * 16 + li;
+          if (mask_epi) {                                      // same arithmetic, same order as apply_epilogue (BG_EPI_BIAS_LRELU)
+            float v = acc[tg][nt][rr] + e_bias[nt];
+            v = v > 0.f ? v : p.alpha * v;
+            if (p.keep_elems == 0 || idx < p.keep_elems) v = e_keep[rr][nt] ? v * p.scale : 0.f;
+            p.C[idx] = v;
+          } else {
+            p.C[idx] = bg::apply_epilogue_pre(p, acc[tg][nt][rr], idx, e_bias[nt], e_mul[nt]);
+          }
         }
-      }
+    }
   }
 }
 
 template <int K>
 int launch_rows_gather(const RowGParams& p, int tg, dim3 grid, size_t lds, hipStream_t s) {
   const int nt = p.N / 16;
-#define BG_RG(TGv, NTv) hipLaunchKernelGGL((conv_rows_gather_kernel<TGv, NTv, K>), grid, dim3(256), lds, s, p)
+  const bool mask = p.epi_mode == BG_EPI_BIAS_LRELU && p.keep != nullptr;
+#define BG_RG(TGv, NTv) do { if (mask) hipLaunchKernelGGL((conv_rows_gather_kernel<TGv, NTv, K, true>), grid, dim3(256), lds, s, p); \
+                             else hipLaunchKernelGGL((conv_rows_gather_kernel<TGv, NTv, K, false>), grid, dim3(256), lds, s, p); } while (0)
   if (tg == 1) { if (nt == 1) BG_RG(1, 1); else if (nt == 2) BG_RG(1, 2); else BG_RG(1, 4); }
   else if (tg == 2) { if (nt == 1) BG_RG(2, 1); else if (nt == 2) BG_RG(2, 2); else BG_RG(2, 4); }
   else { if (nt == 1) BG_RG(4, 1); else if (nt == 2) BG_RG(4, 2); else BG_RG(4, 4); }
