@@ -199,6 +199,56 @@ __device__ inline float apply_epilogue_pre(const P& p, float v, size_t idx, floa
   return v;
 }
 
+// Four consecutive output channels of one pixel at once (16-B aligned: N % 4 == 0, idx % 4 == 0): the same arithmetic as
+// apply_epilogue_pre per component, with the per-element operands (LeakyReLU-gradient reference, dropout mask) fetched as one
+// float4 and one 4-byte word instead of four loads each.
+template <class P>
+__device__ inline float4 apply_epilogue4(const P& p, float4 v, size_t idx, const float* bias4, const float* mul4) {
+  const float4 b = *reinterpret_cast<const float4*>(bias4);
+  if (p.epi_mode == BG_EPI_AFFINE_LRELU) {
+    const float4 m = *reinterpret_cast<const float4*>(mul4);
+    v.x = fmaf(v.x, m.x, b.x); v.y = fmaf(v.y, m.y, b.y); v.z = fmaf(v.z, m.z, b.z); v.w = fmaf(v.w, m.w, b.w);
+    v.x = v.x > 0.f ? v.x : p.alpha * v.x; v.y = v.y > 0.f ? v.y : p.alpha * v.y;
+    v.z = v.z > 0.f ? v.z : p.alpha * v.z; v.w = v.w > 0.f ? v.w : p.alpha * v.w;
+    return v;
+  }
+  v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+  const bool has_mask = p.keep != nullptr;
+  switch (p.epi_mode) {
+    case BG_EPI_BIAS_LRELU: {
+      v.x = v.x > 0.f ? v.x : p.alpha * v.x; v.y = v.y > 0.f ? v.y : p.alpha * v.y;
+      v.z = v.z > 0.f ? v.z : p.alpha * v.z; v.w = v.w > 0.f ? v.w : p.alpha * v.w;
+      if (has_mask) {
+        const uchar4 k = *reinterpret_cast<const uchar4*>(p.keep + ((p.keep_elems == 0 || idx < p.keep_elems) ? idx : 0));
+        if (p.keep_elems == 0 || idx + 0 < p.keep_elems) v.x = k.x ? v.x * p.scale : 0.f;
+        if (p.keep_elems == 0 || idx + 1 < p.keep_elems) v.y = k.y ? v.y * p.scale : 0.f;
+        if (p.keep_elems == 0 || idx + 2 < p.keep_elems) v.z = k.z ? v.z * p.scale : 0.f;
+        if (p.keep_elems == 0 || idx + 3 < p.keep_elems) v.w = k.w ? v.w * p.scale : 0.f;
+      }
+      break;
+    }
+    case BG_EPI_MUL_GRAD: {
+      const float4 r = *reinterpret_cast<const float4*>(p.ref + idx);
+      float f0 = r.x > 0.f ? 1.f : p.alpha, f1 = r.y > 0.f ? 1.f : p.alpha, f2 = r.z > 0.f ? 1.f : p.alpha, f3 = r.w > 0.f ? 1.f : p.alpha;
+      if (has_mask) {
+        const uchar4 k = *reinterpret_cast<const uchar4*>(p.keep + ((p.keep_elems == 0 || idx < p.keep_elems) ? idx : 0));
+        if (p.keep_elems == 0 || idx + 0 < p.keep_elems) f0 = k.x ? f0 * p.scale : 0.f;
+        if (p.keep_elems == 0 || idx + 1 < p.keep_elems) f1 = k.y ? f1 * p.scale : 0.f;
+        if (p.keep_elems == 0 || idx + 2 < p.keep_elems) f2 = k.z ? f2 * p.scale : 0.f;
+        if (p.keep_elems == 0 || idx + 3 < p.keep_elems) f3 = k.w ? f3 * p.scale : 0.f;
+      }
+      v.x *= f0; v.y *= f1; v.z *= f2; v.w *= f3;
+      break;
+    }
+    case BG_EPI_TANH:
+      v.x = tanhf(v.x); v.y = tanhf(v.y); v.z = tanhf(v.z); v.w = tanhf(v.w);
+      break;
+    default:
+      break;
+  }
+  return v;
+}
+
 // conv_rows.hip: row-MFMA kernel for thin-N forward (stride 1) / data gradient; *taken = 0 when the shape is not covered
 int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B, int H, int W, int Cin, int Cout, int k, int s,
                   const bg_epilogue* epi, void* stream, int* taken);

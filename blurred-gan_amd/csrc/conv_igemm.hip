@@ -35,7 +35,7 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // one: the two running sums per accumulator column cost the 64x64 tile its fourth wave per SIMD (103 -> 119 + 16 registers),
 // and the plain variant is the dominant kernel of the step.
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool STATS = false>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(const GatherParams p) {
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64) ? 4 : 1) void conv_igemm_kernel(const GatherParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;     // 4 or 8 waves per workgroup
   static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
   static_assert(BK == 16 || BK == 32, "BK");
@@ -55,6 +55,13 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   __shared__ int rowdst[BM];
   __shared__ int taplist[bg::kMaxTaps];
   __shared__ int phase_steps[bg::kMaxPhases], phase_dd[bg::kMaxPhases];
+  // Accumulators TRANSPOSED (the weights are the MFMA's row operand) in every variant but the statistics one: a lane then ends
+  // with 4 consecutive output channels of one pixel in 4 consecutive registers and the epilogue moves float4 -- 4 stores per
+  // 32 x 32 block instead of 16, and for the epilogues that read per element one float4 + one mask word instead of 4 + 4 loads
+  // (round 3: every vector-memory instruction costs the matrix pipe ~58 cycles wherever it is issued, and the LeakyReLU-gradient
+  // epilogue cost the critic's 32 -> 64 data gradient +24 %).  Needs N % 4 == 0 and 16-byte aligned pointers (host-checked).
+  constexpr bool TR = !STATS;
+  __shared__ __attribute__((aligned(16))) float s_epi[2][BN];      // TR: bias and folded-BatchNorm scale of the tile's columns
 
   // A workgroup owns one output tile of `pm` sub-pixel phases (same anchors, different tap sets and destination offsets).
   // pm = 2 pairs the 9-tap with the 4-tap phase and the two 6-tap phases.
@@ -126,6 +133,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
     int dst;
     bg::decode_row(p, g, m0 + tid, Mph, tmp, dst);
     rowdst[tid] = dst;
+  }
+  if (TR && tid < BN) {
+    const int n = n0 + tid;
+    s_epi[0][tid] = (p.bias && n < p.N) ? p.bias[n] : 0.f;
+    s_epi[1][tid] = (p.epi_mode == BG_EPI_AFFINE_LRELU && n < p.N) ? p.ref[n] : 1.f;
   }
   // Taps whose source pixel is zero padding for EVERY row of the tile are dropped from the K loop (no loads, no MFMAs).
   // Only position-major tiles can lose taps (all their rows sit at ONE output position; a pixel-major tile spans whole image
@@ -254,10 +266,17 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
       for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NI; ++j) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].x, bf[c][j].x, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].y, bf[c][j].y, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].z, bf[c][j].z, acc[i][j], 0, 0, 0);
-          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].w, bf[c][j].w, acc[i][j], 0, 0, 0);
+          if (TR) {                                           // C^T = W^T A^T: same products, same order of the K sum
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[c][j].x, af[c][i].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[c][j].y, af[c][i].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[c][j].z, af[c][i].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(bf[c][j].w, af[c][i].w, acc[i][j], 0, 0, 0);
+          } else {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].x, bf[c][j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].y, bf[c][j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].z, bf[c][j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[c][i].w, bf[c][j].w, acc[i][j], 0, 0, 0);
+          }
         }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -269,7 +288,36 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64) void conv_igemm_kernel(cons
   float st_sum[NI], st_sq[NI];                                // column sums of this lane's accumulator columns (do_stats)
 #pragma unroll
   for (int j = 0; j < NI; ++j) { st_sum[j] = 0.f; st_sq[j] = 0.f; }
+  // TR: acc reg r of lane l holds C[row = l & 31][col = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5)] of the 32 x 32 block
+  auto epilogue_tr = [&](int q) {
+    const int dd = phase_dd[q];
+    const size_t slab_off = (size_t)split * ((size_t)p.B * p.Hd * p.Wd * p.N);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int dst = rowdst[wm * WTM + i * 32 + col];
+#pragma unroll
+      for (int j = 0; j < NI; ++j)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const int nl = wn * WTN + j * 32 + 8 * g4 + rhalf;     // column within the tile: rhalf = 4 * (lane >> 5)
+          const float4 v = make_float4(acc[i][j][4 * g4], acc[i][j][4 * g4 + 1], acc[i][j][4 * g4 + 2], acc[i][j][4 * g4 + 3]);
+          if (dst >= 0 && n0 + nl < p.N) {
+            const size_t idx = (size_t)(dst + dd) * p.N + n0 + nl;
+            if (p.ksplit > 1) {
+              *reinterpret_cast<float4*>(p.slab + slab_off + idx) = v;
+            } else {
+              *reinterpret_cast<float4*>(p.C + idx) = bg::apply_epilogue4(p, v, idx, &s_epi[0][nl], &s_epi[1][nl]);
+            }
+          }
+          acc[i][j][4 * g4] = 0.f; acc[i][j][4 * g4 + 1] = 0.f; acc[i][j][4 * g4 + 2] = 0.f; acc[i][j][4 * g4 + 3] = 0.f;
+        }
+    }
+  };
   auto epilogue = [&](int q) {
+    if (TR) {
+      epilogue_tr(q);
+      return;
+    }
     const int dd = phase_dd[q];
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -997,7 +1045,11 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
   for (int i = 0; i < p.nphase; ++i)
     for (int t = 0; t < p.ph[i].ntaps; ++t) ntap_w = std::max(ntap_w, bg::tap_wi(p.ph[i].tap[t]) + 1);
   const size_t w_bytes = (size_t)ntap_w * p.N * p.Ck * sizeof(float);
-  if (p.Ck % 16 == 0 && p.N > 4 && a_bytes < (1ull << 31) && w_bytes < (1ull << 31)) {
+  // the MFMA kernel moves its output as float4: N % 4 == 0 and 16-byte aligned output / reference / split-K scratch, 4-byte mask
+  const auto al = [](const void* q, size_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
+  const bool vec_ok = p.N % 4 == 0 && al(p.C, 16) && (p.epi_mode != BG_EPI_MUL_GRAD || al(p.ref, 16)) && al(p.keep, 4) &&
+                      (p.keep_elems % 4 == 0) && (!epi || al(epi->splitk_ws, 16));
+  if (p.Ck % 16 == 0 && p.N > 4 && vec_ok && a_bytes < (1ull << 31) && w_bytes < (1ull << 31)) {
     p.a_bytes = (unsigned)a_bytes;
     p.w_bytes = (unsigned)w_bytes;
     snprintf(name, sizeof name, "conv_igemm_%s", tag);

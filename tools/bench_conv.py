@@ -15,6 +15,9 @@ LAYERS = {  # (name, B-mult, H, W, Cin, Cout, stride): conv geometry (H,W,Cin = 
                  # generator ConvT layers expressed as the underlying conv (input side = ConvT output)
                  ("G1 CT512->512 s1", 4, 4, 512, 512, 1), ("G2 CT512->256", 8, 8, 256, 512, 2), ("G3 CT256->128", 16, 16, 128, 256, 2),
                  ("G4 CT128->64", 32, 32, 64, 128, 2), ("G5 CT64->32", 64, 64, 32, 64, 2), ("G6 conv32->3", 64, 64, 32, 3, 1)],
+    # demo_mnist.py:48-86: critic Conv 1->64, 64->128 (stride 2); generator ConvT 256->128 (s1, 7x7), 128->64 (s2), 64->1 (s2, tanh)
+    "mnist": [("D1 1->64", 28, 28, 1, 64, 2), ("D2 64->128", 14, 14, 64, 128, 2), ("G1 CT256->128 s1", 7, 7, 128, 256, 1),
+              ("G2 CT128->64", 14, 14, 64, 128, 2), ("G3 CT64->1", 28, 28, 1, 64, 2)],
     "celeba128": [("D1 3->16", 128, 128, 3, 16, 2), ("D2 16->32", 64, 64, 16, 32, 2), ("D3 32->64", 32, 32, 32, 64, 2),
                   ("D4 64->128", 16, 16, 64, 128, 2), ("D5 128->256", 8, 8, 128, 256, 2), ("D6 256->512", 4, 4, 256, 512, 2),
                   ("G1 CT512->512 s1", 4, 4, 512, 512, 1), ("G2 CT512->256", 8, 8, 256, 512, 2), ("G3 CT256->128", 16, 16, 128, 256, 2),
