@@ -135,7 +135,11 @@ __global__ __launch_bounds__(PIXW * 4) void conv_rows_scatter_kernel(const RowPa
   // Row-independent part of the kw shift-add, per thread: output element e = (image, x, n) of a finished row sums the
   // P columns (kw, n) of the input pixels ix = (x + pl - kw) / S that exist.  Offsets into one P buffer; a term that does not
   // exist reads the slot's zero.
-  constexpr int NE = 3;                                      // output elements per thread: ipw * Wo * N <= 3 * NTH (host-checked)
+  // output elements per thread: a workgroup's PIXW input pixels become PIXW * S output pixels of N <= 16 / K channels over NTH =
+  // 4 * PIXW threads, i.e. ceil(S * N / 4) each (host-checked).  Not a flat 3: an element slot nobody owns still issues its LDS reads
+  // and its (dropped) store every trip, and a vector-memory instruction is ~58 cycles of the SIMD's matrix pipe (69 -> 64 us on the
+  // 16 -> 3 conv of the 128-pixel generator).
+  constexpr int NE = (S * (16 / K) + 3) / 4;
   constexpr int NTERM = (K + S - 1) / S;
   int e_src[NE][NTERM];
   unsigned e_dst[NE];                                        // byte offset of (image, y = 0, x, n) in the workgroup's output, kOob = none
@@ -525,7 +529,7 @@ int try_conv_rows(int bwd_data, const float* a, const float* w, float* c, int B,
   p.wpr = p.Wi / 16;
   p.ipw = p.Wi == 128 ? 1 : 4 / p.wpr;
   const int pixw = p.Wi == 128 ? 128 : 64;
-  if ((long)p.ipw * p.Wo * p.N > 3L * pixw * 4) return BG_OK;                          // output elements per thread of the shift-add
+  if ((long)p.ipw * p.Wo * p.N > (long)((s * (16 / k) + 3) / 4) * pixw * 4) return BG_OK;   // output elements per thread of the shift-add (the kernel's NE)
   if ((size_t)p.ipw * p.Hi * p.Wi * p.Ck >= (1ull << 29) || (size_t)p.ipw * p.Ho * p.Wo * p.N >= (1ull << 29)) return BG_OK;   // a workgroup's images are one buffer: 31-bit byte offsets
   p.epi_mode = BG_EPI_NONE; p.alpha = 0.3f; p.scale = 1.f;
   if (epi) {
