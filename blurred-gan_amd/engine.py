@@ -173,7 +173,10 @@ class Net:
         self._splitk_bytes = {}
         self.rng_offset = 0
         self.sync_bn = True       # data parallel: BatchNormalization statistics over the global batch
-        self.fuse_bn_stats = not os.environ.get("BGAN_NO_FUSED_BN_STATS")   # statistics in the producing conv's epilogue
+        # statistics in the producing conv's epilogue: opt-in since round 3 -- the plain gather-GEMM variant now stores float4
+        # (transposed accumulators), the statistics variant cannot, and the separate statistics pass costs less than that (C2
+        # +0.24 %, C4 +0.3 % in a same-box A/B); BGAN_FUSED_BN_STATS=1 selects the fused form
+        self.fuse_bn_stats = os.environ.get("BGAN_FUSED_BN_STATS") == "1" and not os.environ.get("BGAN_NO_FUSED_BN_STATS")
 
     # ------------------------------------------------------------------ resources
     def context(self, B, tag="default", drop_rows=None) -> Context:

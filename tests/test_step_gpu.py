@@ -273,6 +273,33 @@ def test_merged_penalty_filter_gradients_equal_the_separate_launches(arch, B):
             assert rel_l2(a, b) < 2e-6 or not np.any(b), (kw, a.shape, rel_l2(a, b))
 
 
+@pytest.mark.parametrize("arch,B", [("celeba64", 64), ("celeba128", 4)])
+def test_fused_batchnorm_statistics_equal_the_separate_pass(arch, B):
+    """BatchNorm batch statistics left by the producing conv's epilogue (engine.Net.fuse_bn_stats, opt-in since round 3:
+    BGAN_FUSED_BN_STATS=1) against the separate statistics pass (the default): the same generator gradients and moving statistics up
+    to summation order -- which the BatchNorm backward's cancellation amplifies to the level of the float32 oracle's own
+    deviation from float64 (helpers.GRAD_L2["g"]): the bound on the gradients is that one, the statistics themselves agree to 1e-5."""
+    ref = None
+    for fused in (False, True):
+        gan, st, reals, rng = _make(arch, B, 1.0, seed=6)
+        gan.generator.net().fuse_bn_stats = fused
+        rnd = S.draw_randomness(arch, B, rng, np.float64)
+        gan.discriminator.optimizer.learning_rate = 0.0
+        gan.generator.optimizer.learning_rate = 0.0
+        gan.train_on_batch(reals.astype(np.float32), randomness=rnd)
+        grads = product_grads(gan.generator)
+        moving = [v.detach().cpu().numpy().astype(np.float64) for l in gan.generator.layers
+                  for k, v in getattr(l, "vars", {}).items() if k.startswith("moving_")]
+        if ref is None:
+            ref = (grads, moving)
+            continue
+        assert len(moving) == len(ref[1]) and len(moving) > 0
+        for a, b in zip(moving, ref[1]):
+            assert rel_l2(a, b) < 1e-5, (a.shape, rel_l2(a, b))
+        for a, b in zip(grads, ref[0]):
+            assert rel_l2(a, b) < 2e-3 and cosine(a, b) > 1 - 1e-5 or not np.any(b), (a.shape, rel_l2(a, b), cosine(a, b))
+
+
 def test_vector_loss_quirk_switch():
     """Q1 on/off changes the critic gradient exactly by the documented factor on the W + GP part."""
     arch, B = "tiny", 4
