@@ -119,10 +119,10 @@ typedef struct {
 
 /* bytes of split-K scratch the forward (bwd_data = 0) / data-gradient (bwd_data = 1) call can use; 0 = never splits */
 size_t bg_conv2d_splitk_workspace_bytes(int bwd_data, int B, int H, int W, int Cin, int Cout, int ksize, int stride);
-/* Alignment: any 4-byte aligned float pointers are accepted.  The matrix-core kernels move their output as float4: they are
- * taken when the output (and, with it, bias / ref / the split-K scratch) is 16-byte aligned, the mask 4-byte aligned with
- * keep_elems % 4 == 0, and the output channel count a multiple of 4 -- what a framework allocator hands out; anything else runs
- * on the direct kernel (same results, slower). */
+/* Alignment: x / w / y (dy / w / dx) must be 16-byte aligned (BG_ERR_BAD_ALIGNMENT otherwise).  The epilogue's operands may sit
+ * anywhere, but the matrix-core kernels read them four at a time: they are taken when bias / ref / the split-K scratch are
+ * 16-byte aligned, the mask 4-byte aligned with keep_elems % 4 == 0, and the output channel count a multiple of 4 -- what a
+ * framework allocator hands out; anything else runs on the direct kernel (same results, slower). */
 /* y[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w) ; wT_d = [k*k][Cout][Cin] */
 int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int W, int Cin, int Cout,
                   int ksize, int stride, const bg_epilogue* epi, void* stream);

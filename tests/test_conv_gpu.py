@@ -215,6 +215,47 @@ def test_thin_n_row_kernel_epilogues(B, HW):
     np.testing.assert_allclose(dx.cpu().numpy(), expd, rtol=1e-4, atol=2 * told)
 
 
+def test_unaligned_epilogue_operands_take_the_direct_kernel():
+    """x / w / y must be 16-byte aligned (the call fails loudly otherwise); the epilogue's operands need not be.  The matrix-core
+    kernels read them four at a time (include/bgan.h), so a reference tensor that starts 4 bytes into an allocation or a mask that
+    starts at an odd byte sends the call to the direct kernel -- same results."""
+    from blurred_gan_amd import ops
+    from blurred_gan_amd._lib import EPI_BIAS_LRELU, EPI_MUL_GRAD
+    B, H, W, Ci, Co, s = 3, 16, 16, 32, 64, 2
+    x, w, dy = _data(B, H, W, Ci, Co, s, seed=21)
+    rng = np.random.default_rng(22)
+    bias = rng.normal(size=Co)
+    z = O.conv2d_fwd(x, w, s) + bias
+    keep = (rng.uniform(size=z.shape) >= 0.3).astype(np.uint8)
+    wT = dev(np.transpose(w, (0, 1, 3, 2)))
+    exp = O.dropout_fwd(O.lrelu_fwd(z), keep, 0.3)
+    tol = conv_tol(25 * Ci, np.abs(z).max())
+    ref_act = rng.normal(size=x.shape)
+    keep_x = (rng.uniform(size=x.shape) >= 0.3).astype(np.uint8)
+    dxr = O.conv2d_bwd_data(dy, w, s, (H, W))
+    expd = dxr * O.lrelu_mask(ref_act) * keep_x / 0.7
+    told = conv_tol(25 * Co, np.abs(dxr).max())
+
+    def shifted(a, dtype, shift):
+        buf = torch.empty(a.size + 8, device="cuda", dtype=dtype)
+        v = buf[shift:shift + a.size].view(a.shape)
+        v.copy_(dev(a, dtype))
+        return v
+
+    for shift in (0, 1):
+        y = ops.conv2d_fwd(dev(x), wT, torch.empty(z.shape, device="cuda"), 5, s,
+                           ops.epilogue(EPI_BIAS_LRELU, bias=shifted(bias, torch.float32, shift), keep=shifted(keep, torch.uint8, shift),
+                                        alpha=0.3, scale=1 / 0.7))
+        np.testing.assert_allclose(y.cpu().numpy(), exp, rtol=1e-4, atol=2 * tol)
+        dx = ops.conv2d_bwd_data(dev(dy), dev(w), torch.empty(x.shape, device="cuda"), 5, s,
+                                 ops.epilogue(EPI_MUL_GRAD, ref=shifted(ref_act, torch.float32, shift), keep=shifted(keep_x, torch.uint8, shift),
+                                              alpha=0.3, scale=1 / 0.7))
+        np.testing.assert_allclose(dx.cpu().numpy(), expd, rtol=1e-4, atol=2 * told)
+    ybuf = torch.empty(z.size + 4, device="cuda")
+    with pytest.raises(ValueError, match="16-byte aligned"):
+        ops.conv2d_fwd(dev(x), wT, ybuf[1:1 + z.size].view(z.shape), 5, s)
+
+
 def test_conv_transpose_roles():
     """Conv2DTranspose forward = bwd_data with the kernel array as is; its filter gradient swaps x and dy."""
     from blurred_gan_amd import ops
