@@ -112,32 +112,51 @@ __global__ __launch_bounds__(256) void conv_c16_dgrad_kernel(const C16Params p) 
     for (int py = 0; py < 2; ++py) {
       floatx4 acc[2][MT];
 #pragma unroll
-      for (int px = 0; px < 2; ++px) {
+      for (int px = 0; px < 2; ++px)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[px][mt] = floatx4{0.f, 0.f, 0.f, 0.f};
+      // Both column phases in one pass: kernel columns 0, 2, 4 belong to px = 1, columns 1, 3 to px = 0, so taking them in pairs
+      // (0, 1), (2, 3), (4) makes consecutive MFMAs write DIFFERENT accumulators -- with the px loop outside, the 32-column
+      // variant issued 195 of its 200 MFMAs per strip as one dependent chain, each waiting for the one before (round 3).  Every
+      // accumulator still sees its products in the order (kh, kw, channel half, k component): results unchanged.
 #pragma unroll
-        for (int kh = 0; kh < 5; ++kh) {
-          if (((py + 1 - kh) & 1) != 0) continue;
-          const int dy = (py + 1 - kh) / 2;
+      for (int kh = 0; kh < 5; ++kh) {
+        if (((py + 1 - kh) & 1) != 0) continue;
+        const int dy = (py + 1 - kh) / 2;
 #pragma unroll
-          for (int kw = 0; kw < 5; ++kw) {
-            if (((px + 1 - kw) & 1) != 0) continue;
-            const int dx = (px + 1 - kw) / 2;
-            const float* ap = rb + dy * RSTR + dx * kDgAst;
-            const float* bp = wb + (kh * 5 + kw) * 16 * kDgAst;
+        for (int g = 0; g < 3; ++g) {
+          const int kwA = 2 * g, kwB = 2 * g + 1;             // px = 1 takes kwA (dx = (2 - kwA) / 2), px = 0 takes kwB (dx = (1 - kwB) / 2)
+          const float* apA = rb + dy * RSTR + ((2 - kwA) / 2) * kDgAst;
+          const float* bpA = wb + (kh * 5 + kwA) * 16 * kDgAst;
+          const float* apB = rb + dy * RSTR + ((1 - kwB) / 2) * kDgAst;
+          const float* bpB = wb + (kh * 5 + kwB) * 16 * kDgAst;
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const float4 bv = *reinterpret_cast<const float4*>(bp + 16 * h);
+          for (int h = 0; h < 2; ++h) {
+            const float4 bvA = *reinterpret_cast<const float4*>(bpA + 16 * h);
+            float4 avA[MT], avB[MT];
+            float4 bvB = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-                const float4 av = *reinterpret_cast<const float4*>(ap + mt * 16 * kDgAst + 16 * h);
-                // weights are the MFMA's row operand: D[i = channel][j = anchor], so a lane ends up with 4 consecutive channels
-                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.x, av.x, acc[px][mt], 0, 0, 0);
-                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.y, av.y, acc[px][mt], 0, 0, 0);
-                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.z, av.z, acc[px][mt], 0, 0, 0);
-                acc[px][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv.w, av.w, acc[px][mt], 0, 0, 0);
-              }
+            for (int mt = 0; mt < MT; ++mt) avA[mt] = *reinterpret_cast<const float4*>(apA + mt * 16 * kDgAst + 16 * h);
+            if (kwB < 5) {
+              bvB = *reinterpret_cast<const float4*>(bpB + 16 * h);
+#pragma unroll
+              for (int mt = 0; mt < MT; ++mt) avB[mt] = *reinterpret_cast<const float4*>(apB + mt * 16 * kDgAst + 16 * h);
             }
+            // weights are the MFMA's row operand: D[i = channel][j = anchor], so a lane ends up with 4 consecutive channels
+#define BG_C16_STEP(c)                                                                                                   \
+  do {                                                                                                                    \
+    _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                                     \
+        acc[1][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bvA.c, avA[mt].c, acc[1][mt], 0, 0, 0);                          \
+    if (kwB < 5) {                                                                                                        \
+      _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                                   \
+          acc[0][mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(bvB.c, avB[mt].c, acc[0][mt], 0, 0, 0);                        \
+    }                                                                                                                     \
+  } while (0)
+            BG_C16_STEP(x);
+            BG_C16_STEP(y);
+            BG_C16_STEP(z);
+            BG_C16_STEP(w);
+#undef BG_C16_STEP
           }
         }
       }
@@ -272,14 +291,19 @@ __global__ __launch_bounds__(256) void conv_c16_fwd_kernel(const C16Params p) {
       for (int kw = 0; kw < 5; ++kw) {
         const int par = (kw + 1) & 1, fl = kw == 0 ? -1 : (kw - 1) / 2;
         const float4 wv = wf[kh * 5 + kw];
+        // consecutive MFMAs go to DIFFERENT accumulators (k component outer, pixel tile inner): a chain of four on one accumulator
+        // waits for each result in turn.  Every accumulator still sees its products in the same order: results unchanged.
+        float4 xv[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-          const float4 xv = *reinterpret_cast<const float4*>(xb + kh * RS + par * PS + (mt * 16 + fl) * kFwPst);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv.x, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv.y, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv.z, acc[mt], 0, 0, 0);
-          acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv.w, acc[mt], 0, 0, 0);
-        }
+        for (int mt = 0; mt < MT; ++mt) xv[mt] = *reinterpret_cast<const float4*>(xb + kh * RS + par * PS + (mt * 16 + fl) * kFwPst);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.x, xv[mt].x, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.y, xv[mt].y, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.z, xv[mt].z, acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv.w, xv[mt].w, acc[mt], 0, 0, 0);
       }
     // reg rr of lane (li, kq) = out[pixel 16*mt + li][channel 16*nt + 4*kq + rr]
     const size_t rowbase = ((size_t)b * p.Hd + oy) * WO;
