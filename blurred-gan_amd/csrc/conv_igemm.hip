@@ -72,7 +72,10 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64) ? 4 
   if (p.order_n > 0) {
     // cost-sorted snake (GatherParams::pp_order): 1-D grid, workgroup w sits on CU slot w % 256 in residency round w / 256
     const int w = blockIdx.x, r = w >> 8;
-    const int u = ((r & 1) && ((r + 1) << 8) <= (int)gridDim.x) ? (r << 8) + 255 - (w & 255) : w;
+    // odd rounds walk the CUs backwards but keep the XCD (w % 8): the N tile below is u % nt, so an XCD sees the same weight panel
+    // in every round -- with the plain reversal 255 - (w & 255) it saw panels x and 7 - x, 6.6 MB of weights on the 512-channel
+    // layers against 4 MB of L2, and re-fetched them ten times over (round 3 counters)
+    const int u = ((r & 1) && ((r + 1) << 8) <= (int)gridDim.x) ? (r << 8) + ((31 - ((w & 255) >> 3)) << 3) + (w & 7) : w;
     const int pair = u / p.per_pair;
     int rest = u - pair * p.per_pair;
     const int code = p.pp_order[pair];

@@ -71,7 +71,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
   if (P2 == 2 && p.order_n > 0) {
     // workgroup w sits on CU slot w % 256 in residency round w / 256 (tools/probes/placement.hip): cost-sorted snake
     const int w = blockIdx.x, r = w >> 8;
-    const int u = ((r & 1) && ((r + 1) << 8) <= (int)gridDim.x) ? (r << 8) + 255 - (w & 255) : w;
+    // odd rounds walk the CUs backwards but keep the XCD (w % 8), as in conv_igemm_kernel: an XCD sees the same channel tiles in every round
+    const int u = ((r & 1) && ((r + 1) << 8) <= (int)gridDim.x) ? (r << 8) + ((31 - ((w & 255) >> 3)) << 3) + (w & 7) : w;
     tile = u % ntile;
     const int rest = u / ntile;
     zsplit = rest % p.ksplit;
