@@ -48,6 +48,9 @@ struct GatherParams {
   unsigned char grp_order[4];      // plain order: phase groups by descending tap count (grid.z walks them heaviest first, so a multi-round
                                    // grid ends on its SHORT workgroups: the 4-tap phase of a stride-2 transposed conv, not the 9-tap one)
   int order_n;         // pairs in pp_order (0 = plain (n tile, m tile) x (phase, split) order)
+  int m_fast;          // sorted order, inside a pair: 0 = N tile fastest (an XCD keeps ONE weight panel: weight-heavy layers),
+                       // 1 = batch slice fastest (the N tiles of a slice follow each other on ONE XCD and hit its L2 for the
+                       // activation rows: layers whose weights fit an L2 and whose activations are the bigger operand)
   int per_pair;        // workgroups per pair = ksplit * N tiles * (B / BM)
   unsigned char pp_order[256];     // (phase group << 6) | position, by descending cost
   // epilogue

@@ -81,10 +81,18 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64) ? 4 
     const int code = p.pp_order[pair];
     const int nt = (p.N + BN - 1) / BN, bch = p.B / BM;
     pgrp = code >> 6;
-    n_tile = rest % nt;           // N tile fastest: with 8 tiles a weight panel stays on one XCD (w % 8), two panels on odd rounds
-    rest /= nt;
-    split = rest / bch;
-    m_tile = (code & 63) * bch + (rest - split * bch);
+    if (p.m_fast) {
+      const int msib = rest % bch;
+      rest /= bch;
+      n_tile = rest % nt;
+      split = rest / nt;
+      m_tile = (code & 63) * bch + msib;
+    } else {
+      n_tile = rest % nt;           // N tile fastest: with 8 tiles a weight panel stays on one XCD (w % 8) in every round
+      rest /= nt;
+      split = rest / bch;
+      m_tile = (code & 63) * bch + (rest - split * bch);
+    }
   } else {
     // logical tile list is n-major (all M tiles of one weight panel, then the next panel): with the XCD remap each
     // XCD's L2 holds only its share of the weight panels while the activations stream through
@@ -939,6 +947,7 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
   }
   dim3 grid(p.mtiles * bg::cdiv(p.N, BN), 1, (p.nphase / p.pmerge) * ks);
   p.order_n = 0;
+  p.m_fast = 0;
   static const int no_sort = getenv("BG_NO_TILE_SORT") ? 1 : 0;
   {
     const int pm = p.pmerge, ngroups = p.nphase / pm;
@@ -977,6 +986,10 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
       for (int i = 0; i < n; ++i) p.pp_order[i] = (unsigned char)v[i].code;
       p.order_n = n;
       p.per_pair = ks * (int)bg::cdiv(p.N, BN) * (p.B / BM);
+      static const int mfast_env = getenv("BG_MFAST") ? atoi(getenv("BG_MFAST")) : -1;
+      const size_t l2 = (size_t)4 << 20;
+      p.m_fast = bg::cdiv(p.N, BN) > 1 && p.w_bytes <= l2 && (size_t)p.a_bytes >= 2 * (size_t)p.w_bytes;
+      if (mfast_env >= 0) p.m_fast = mfast_env;
       grid = dim3((unsigned)(n * p.per_pair), 1, 1);
     }
   }
