@@ -748,11 +748,23 @@ __global__ __launch_bounds__(256) void conv_direct_kernel(const GatherParams p) 
 }
 
 // split-K tail: C = epilogue(sum over splits of the partial slabs)
+// Four consecutive channels per thread (the MFMA path has N % 4 == 0, 16-byte aligned slabs and output, tensors < 2^31 elements):
+// float4 loads of every slab, one epilogue of four, one float4 store -- and 32-bit index arithmetic (the scalar form paid a 64-bit
+// modulo per element).  Slabs are summed in split order: deterministic.
 __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const GatherParams p, size_t total) {
-  for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
-    float s = 0.f;
-    for (int z = 0; z < p.ksplit; ++z) s += p.slab[(size_t)z * total + e];
-    p.C[e] = bg::apply_epilogue(p, s, e, (int)(e % p.N));
+  const unsigned total4 = (unsigned)(total >> 2);
+  for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < total4; q += gridDim.x * 256u) {
+    const unsigned e = q * 4u;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int z = 0; z < p.ksplit; ++z) {
+      const float4 v = *reinterpret_cast<const float4*>(p.slab + (size_t)z * total + e);
+      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    }
+    const unsigned n = e % (unsigned)p.N;
+    float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (p.bias) b4 = *reinterpret_cast<const float4*>(p.bias + n);
+    if (p.epi_mode == BG_EPI_AFFINE_LRELU) m4 = *reinterpret_cast<const float4*>(p.ref + n);
+    *reinterpret_cast<float4*>(p.C + e) = bg::apply_epilogue4(p, s, e, reinterpret_cast<const float*>(&b4), reinterpret_cast<const float*>(&m4));
   }
 }
 
@@ -1013,7 +1025,7 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
     if (rc || ks == 1) return rc;
   }
   bg::Launch L(stream, "conv_igemm_splitk_reduce", 0, (double)(ks + 1) * total * 4);
-  hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)std::min<size_t>(bg::cdiv(total, 256), 2048)), dim3(256), 0, L.s, p, total);
+  hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)std::min<size_t>(bg::cdiv(total / 4, 256), 2048)), dim3(256), 0, L.s, p, total);
   return L.done("igemm_splitk_reduce_kernel");
 }
 
@@ -1063,7 +1075,8 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
   const size_t w_bytes = (size_t)ntap_w * p.N * p.Ck * sizeof(float);
   // the MFMA kernel moves its output as float4: N % 4 == 0 and 16-byte aligned output / reference / split-K scratch, 4-byte mask
   const auto al = [](const void* q, size_t a) { return (reinterpret_cast<uintptr_t>(q) & (a - 1)) == 0; };
-  const bool vec_ok = p.N % 4 == 0 && al(p.C, 16) && (p.epi_mode != BG_EPI_MUL_GRAD || al(p.ref, 16)) && al(p.keep, 4) &&
+  const bool vec_ok = p.N % 4 == 0 && al(p.C, 16) && al(p.bias, 16) &&
+                      ((p.epi_mode != BG_EPI_MUL_GRAD && p.epi_mode != BG_EPI_AFFINE_LRELU) || al(p.ref, 16)) && al(p.keep, 4) &&
                       (p.keep_elems % 4 == 0) && (!epi || al(epi->splitk_ws, 16));
   if (p.Ck % 16 == 0 && p.N > 4 && vec_ok && a_bytes < (1ull << 31) && w_bytes < (1ull << 31)) {
     p.a_bytes = (unsigned)a_bytes;
