@@ -45,7 +45,8 @@ __device__ inline int floordiv(int a, int b) { return a >= 0 ? a / b : -((-a + b
 // form  sign(x) (1 - 2 / (e^(2|x|) + 1))  (absolute error ~ 2e-7, the hardware exp2 and reciprocal), and below |x| = 0.1, where
 // that form loses RELATIVE accuracy, the odd series through x^7 (next term 2e-11).  Selected, not branched.
 __device__ inline float tanh_branchless(float x) {
-  const float ax = fminf(fabsf(x), 15.f);
+  float ax = fabsf(x);
+  ax = ax > 15.f ? 15.f : ax;                                 // a comparison, not fminf: a NaN stays a NaN (tanhf's behaviour)
   const float e = __builtin_amdgcn_exp2f(ax * 2.885390081777927f);          // e^(2 ax)
   const float big = 1.f - 2.f * __builtin_amdgcn_rcpf(e + 1.f);
   const float x2 = ax * ax;

@@ -256,6 +256,26 @@ def test_unaligned_epilogue_operands_take_the_direct_kernel():
         ops.conv2d_fwd(dev(x), wT, ybuf[1:1 + z.size].view(z.shape), 5, s)
 
 
+def test_thin_n_row_kernel_tanh_keeps_nan_and_saturates():
+    """The branch-free tanh of the thin-N row kernel: a NaN in the pre-activation stays a NaN (as with tanhf), huge values give +-1."""
+    from blurred_gan_amd import ops
+    from blurred_gan_amd._lib import EPI_TANH
+    B, HW, Ci, Co = 1, 16, 32, 3
+    x = np.zeros((B, HW, HW, Ci))
+    w = np.zeros((5, 5, Ci, Co))
+    w[2, 2, 0, :] = 1.0                                           # y[..., n] = x[..., 0]
+    x[0, 2, 2, 0] = np.nan                                        # (0 * NaN = NaN reaches the 5 x 5 neighbourhood: keep the probes apart)
+    x[0, 8, 8, 0] = 1e30
+    x[0, 12, 12, 0] = -1e30
+    x[0, 8, 13, 0] = 0.05
+    wT = dev(np.transpose(w, (0, 1, 3, 2)))
+    y = ops.conv2d_fwd(dev(x), wT, torch.empty((B, HW, HW, Co), device="cuda"), 5, 1, ops.epilogue(EPI_TANH)).cpu().numpy()
+    assert np.isnan(y[0, 2, 2]).all()
+    assert (y[0, 8, 8] == 1.0).all() and (y[0, 12, 12] == -1.0).all()
+    np.testing.assert_allclose(y[0, 8, 13], np.tanh(0.05), rtol=2e-6)
+    assert np.isfinite(y[0, 6:]).all()
+
+
 def test_conv_transpose_roles():
     """Conv2DTranspose forward = bwd_data with the kernel array as is; its filter gradient swaps x and dy."""
     from blurred_gan_amd import ops
