@@ -21,6 +21,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC for RCCL; read at the first HIP call (see blurred_gan_amd/__init__.py)
 import torch  # noqa: E402
 
 PEAK_MFMA_F32_TFLOPS = 157.3        # MI355X_MICROARCH.md: dense fp32-input MFMA peak
