@@ -848,12 +848,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_co_kernel(const WgradPara
     const int b = blk / blocks_per_img, y0 = (blk - b * blocks_per_img) * kTcRows;
     __syncthreads();                                          // previous block's fragments consumed
     // dy rows y0 - pt .. y0 + kTcRows - 1 + (K - 1 - pt), zero outside the image, zero halos
-    for (int idx = tid; idx < nrows * RS; idx += 256) {
-      const int r = idx / RS, c = idx - r * RS;
-      const int oy = y0 - (K - 1 - p.pt) + r, e = c - kTcHalo;
-      float v = 0.f;
-      if ((unsigned)oy < (unsigned)p.Ho && (unsigned)e < (unsigned)(W * Co)) v = p.DY[((size_t)b * p.Ho + oy) * W * Co + e];
-      tc_lds[idx] = v;
+    if (((W * Co) & 3) == 0) {                                // float4-addressable rows (see conv_wgrad_thin_ci_kernel)
+      const int q4 = RS / 4;
+      for (int idx = tid; idx < nrows * q4; idx += 256) {
+        const int r = idx / q4, c4 = idx - r * q4;
+        const int oy = y0 - (K - 1 - p.pt) + r, e = c4 * 4 - kTcHalo;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)oy < (unsigned)p.Ho && (unsigned)e < (unsigned)(W * Co)) v = *reinterpret_cast<const float4*>(p.DY + ((size_t)b * p.Ho + oy) * W * Co + e);
+        *reinterpret_cast<float4*>(tc_lds + (size_t)r * RS + c4 * 4) = v;
+      }
+    } else {
+      for (int idx = tid; idx < nrows * RS; idx += 256) {
+        const int r = idx / RS, c = idx - r * RS;
+        const int oy = y0 - (K - 1 - p.pt) + r, e = c - kTcHalo;
+        float v = 0.f;
+        if ((unsigned)oy < (unsigned)p.Ho && (unsigned)e < (unsigned)(W * Co)) v = p.DY[((size_t)b * p.Ho + oy) * W * Co + e];
+        tc_lds[idx] = v;
+      }
     }
     __syncthreads();
     // this wave's work list: (row r = wave + 4*j, pixel group g of 32) flattened; the x registers of item it+1 are
@@ -949,12 +960,25 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_ci_kernel(const WgradPara
     const int b = blk / blocks_per_img, oy0 = (blk - b * blocks_per_img) * RB;
     __syncthreads();
     // x rows oy0*s - pt .. , zero outside the image, zero halos
-    for (int idx = tid; idx < nrows * RS; idx += 256) {
-      const int r = idx / RS, c = idx - r * RS;
-      const int yy = oy0 * st - p.pt + r, e = c - kTiHalo;
-      float v = 0.f;
-      if ((unsigned)yy < (unsigned)H && (unsigned)e < (unsigned)(W * Ci)) v = p.X[((size_t)b * H + yy) * W * Ci + e];
-      ti_lds[idx] = v;
+    if (((W * Ci) & 3) == 0) {
+      // rows are float4-addressable (x is 16-byte aligned, the halo is 16 floats): a quarter of the load instructions of the
+      // scalar copy below, which issued 31 dword loads per thread and block on the 128-pixel critic (round 3)
+      const int q4 = RS / 4;
+      for (int idx = tid; idx < nrows * q4; idx += 256) {
+        const int r = idx / q4, c4 = idx - r * q4;
+        const int yy = oy0 * st - p.pt + r, e = c4 * 4 - kTiHalo;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)yy < (unsigned)H && (unsigned)e < (unsigned)(W * Ci)) v = *reinterpret_cast<const float4*>(p.X + ((size_t)b * H + yy) * W * Ci + e);
+        *reinterpret_cast<float4*>(ti_lds + (size_t)r * RS + c4 * 4) = v;
+      }
+    } else {
+      for (int idx = tid; idx < nrows * RS; idx += 256) {
+        const int r = idx / RS, c = idx - r * RS;
+        const int yy = oy0 * st - p.pt + r, e = c - kTiHalo;
+        float v = 0.f;
+        if ((unsigned)yy < (unsigned)H && (unsigned)e < (unsigned)(W * Ci)) v = p.X[((size_t)b * H + yy) * W * Ci + e];
+        ti_lds[idx] = v;
+      }
     }
     __syncthreads();
     const int myrows = min(RB, Ho - oy0);
