@@ -27,7 +27,7 @@ def _stream():
     cur = _get_device()
     if _dev_index is not None and cur != _dev_index:
         raise BgDeviceError(f"operands live on cuda:{_dev_index} but the current device is cuda:{cur}")
-    return C.c_void_p(_raw_stream(cur))
+    return _raw_stream(cur)            # a plain int: the bindings declare the parameter as c_void_p and ctypes converts
 
 
 def _ptr(t):
@@ -47,7 +47,7 @@ def _ptr(t):
         _dev_index = cur
     if not t.is_contiguous():
         raise ValueError("tensor must be contiguous")
-    return C.c_void_p(t.data_ptr())
+    return t.data_ptr()                # a plain int (c_void_p parameter): one Python object less per operand and launch
 
 
 class BgDeviceError(RuntimeError):
