@@ -19,7 +19,7 @@ class Epilogue(C.Structure):
                 ("keep_elems", C.c_size_t), ("stats", C.c_void_p), ("stats_capacity", C.c_size_t), ("stats_rows", C.POINTER(C.c_int))]
 
 
-ABI_VERSION = 3           # include/bgan.h BG_ABI_VERSION
+ABI_VERSION = 4           # include/bgan.h BG_ABI_VERSION
 EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_AFFINE_LRELU = 0, 1, 2, 3, 4
 
 _p, _i, _f, _z, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
@@ -73,12 +73,27 @@ SIGNATURES = {
     "bg_outer_f32": (_i, [_p, _p, _p, _i, _i, _p]),
     "bg_fill_f32": (_i, [_p, _f, _z, _p]),
     "bg_scale_f32": (_i, [_p, _f, _z, _p]),
+    "bg_copy_f32": (_i, [_p, _p, _z, _p]),
     "bg_wgangp_d_loss": (_i, [_p, _p, _p, _i, _f, _f, _f, _f, _p, _p, _p, _p]),
     "bg_wgan_g_loss": (_i, [_p, _i, _f, _p, _p, _p]),
     "bg_u8_normalize_resize_f32": (_i, [_p, _p, _i, _i, _i, _i, _i, _i, _p]),
     "bg_adam_f32": (_i, [_p, _p, _p, _p, _z, _f, _f, _f, _f, _p]),
     "bg_uniform_f32": (_i, [_p, _z, _u64, _u64, _p]),
     "bg_keep_mask_u8": (_i, [_p, _z, _f, _u64, _u64, _p]),
+    "bg_program_create": (_i, [C.POINTER(_p), _i]),
+    "bg_program_destroy": (_i, [_p]),
+    "bg_program_record_begin": (_i, [_p]),
+    "bg_program_record_end": (_i, [_p]),
+    "bg_program_size": (_i, [_p]),
+    "bg_program_launches": (_i, [_p]),
+    "bg_program_binds": (_i, [_p]),
+    "bg_program_bind_next": (_i, [_i, _i]),
+    "bg_program_slots_f64": (_p, [_p]),
+    "bg_program_slots_u64": (_p, [_p]),
+    "bg_program_replay": (_i, [_p, _i, _i, _p]),
+    "bg_program_graph_launch": (_i, [_p, _i, _i, _p]),
+    "bg_dstep": (_i, [_p, _p]),
+    "bg_gstep": (_i, [_p, _p]),
     "bg_comm_unique_id": (_i, [C.c_char_p]),
     "bg_comm_init": (_i, [C.POINTER(_p), _i, _i, C.c_char_p]),
     "bg_allreduce_sum_f32": (_i, [_p, _p, _z, _p]),
@@ -86,6 +101,7 @@ SIGNATURES = {
 }
 
 COMM_ID_BYTES = 128
+BIND_ADAM_LR, BIND_RNG_OFFSET = 1, 2      # include/bgan.h BG_BIND_*
 
 _lib = None
 

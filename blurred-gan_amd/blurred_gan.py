@@ -34,8 +34,12 @@ def BlurredVariant(some_gan_base_class):
 
         def discriminator_step(self, reals):
             disc_loss, images = super().discriminator_step(reals)
-            self.std_metric(float(self.std))                                     # blurred_gan.py:47
+            self._after_d_step()
             return disc_loss, images
+
+        def _after_d_step(self):
+            """Host side of the step (also run when train_on_batch replays the recorded step program)."""
+            self.std_metric(float(self.std))                                     # blurred_gan.py:47
 
     BlurredGAN.__name__ = BlurredGAN.__qualname__ = "Blurred" + some_gan_base_class.__name__
     return BlurredGAN

@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbgan_hip.so")
-SOURCES = ["runtime.hip", "blur.hip", "conv_igemm.hip", "conv_rows.hip", "conv_c16.hip", "conv_wgrad.hip", "misc.hip", "comm.hip"]
+SOURCES = ["runtime.hip", "blur.hip", "conv_igemm.hip", "conv_rows.hip", "conv_c16.hip", "conv_wgrad.hip", "misc.hip", "comm.hip", "program.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]   # fp contraction off: fmaf() is explicit where wanted
@@ -58,7 +58,7 @@ def build_lib(force=False, verbose=True, flags=None, lib=None, odir=None, post_c
     link_extra = []
     if post_compile is not None and (jobs or not os.path.exists(lib)):
         link_extra = post_compile(objs, run)
-    if jobs or not os.path.exists(lib):
+    if jobs or not os.path.exists(lib) or any(_newer(o, lib) for o in objs):      # objects newer than the library: a build that died before the link
         run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *link_extra, *objs, "-ldl", "-o", lib])
     return lib
 

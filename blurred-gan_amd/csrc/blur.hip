@@ -653,7 +653,7 @@ void launch_band_t(hipStream_t s, const float* src, float* dst, int B, int R, in
   int ld = !off32 ? 0 : (((S * C) & 3) == 0 && ((uintptr_t)src & 15) == 0) ? 2 : 1;
   if (const char* f = getenv("BG_BLUR_BAND_LD")) ld = std::min(ld, std::max(0, atoi(f)));    // test aid: force a slower loader (read per call)
   auto kern = ld == 2 ? blur_band_t_kernel<C, 2> : ld == 1 ? blur_band_t_kernel<C, 1> : blur_band_t_kernel<C, 0>;
-  hipLaunchKernelGGL(kern, grid, dim3(G::NTH), lds, s, src, dst, R, S, rgs, cgs, taps, T);
+  bg::launch(kern, grid, dim3(G::NTH), lds, s, src, dst, R, S, rgs, cgs, taps, T);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -936,7 +936,7 @@ int launch_cols(hipStream_t s, const float* x, float* y, int B, int H, int W, co
   const dim3 grid((unsigned)(8 * bg::cdiv(B, 8) * wpi));
   auto kern = blur_cols_kernel<C, P>;
   const size_t lds = K::lds_bytes;
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, y, B, H, W, strips, segs, seg_rows, taps, T STRIP_DBG_ARG);
+  bg::launch(kern, grid, dim3(256), lds, s, x, y, B, H, W, strips, segs, seg_rows, taps, T STRIP_DBG_ARG);
   return BG_OK;
 }
 
@@ -1249,7 +1249,7 @@ int launch_strip(dim3 grid, hipStream_t s, const float* x, float* y, int B, int 
     if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "blur_strip: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr = true;
   }
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, x, y, B, H, W, strips, taps, T STRIP_DBG_ARG);
+  bg::launch(kern, grid, dim3(256), lds, s, x, y, B, H, W, strips, taps, T STRIP_DBG_ARG);
   return BG_OK;
 }
 
@@ -1365,7 +1365,7 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
       attr_r = true;
     }
     bg::Launch L(stream, "blur_rows", flops, bytes);
-    hipLaunchKernelGGL(blur_rows_kernel, dim3((unsigned)(B * g.nb)), dim3(kRowsThreads), g.lds, s, x, y, H, W, C, g.nb, g.Qp, g.Wp, g.xfloats,
+    bg::launch(blur_rows_kernel, dim3((unsigned)(B * g.nb)), dim3(kRowsThreads), g.lds, s, x, y, H, W, C, g.nb, g.Qp, g.Wp, g.xfloats,
                        taps_d, n_taps, magic((unsigned)(g.Q / 4)));
     return L.done("blur_rows_kernel");
   }
@@ -1380,7 +1380,7 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
         attr_m = true;
       }
       bg::Launch L(stream, "blur_mfma", flops, bytes);
-      hipLaunchKernelGGL(blur_mfma_kernel, dim3(B), dim3(kMfmaBlurThreads), lds_m, s, x, y, H, W, C, Hp, Wp, taps_d, n_taps, magic((unsigned)C),
+      bg::launch(blur_mfma_kernel, dim3(B), dim3(kMfmaBlurThreads), lds_m, s, x, y, H, W, C, Hp, Wp, taps_d, n_taps, magic((unsigned)C),
                          magic((unsigned)W));
       return L.done("blur_mfma_kernel");
     }
@@ -1410,7 +1410,7 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
       attr_set = true;
     }
     bg::Launch L(stream, "blur_fused", flops, bytes);
-    hipLaunchKernelGGL(blur_fused_kernel, dim3(B), dim3(kFusedThreads), lds, s, x, y, H, W, C, taps_d, n_taps);
+    bg::launch(blur_fused_kernel, dim3(B), dim3(kFusedThreads), lds, s, x, y, H, W, C, taps_d, n_taps);
     return L.done("blur_fused_kernel");
   }
   BG_REQUIRE(tmp_d != nullptr, BG_ERR_WORKSPACE, "bg_blur_nhwc_f32: image of %zu bytes needs tmp_d (see bg_blur_workspace_bytes)",
@@ -1452,25 +1452,25 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
     const int strips = (int)bg::cdiv(WC, kStripW);
     {
       bg::Launch L(stream, "blur_lines_h", flops / 2, bytes);
-      hipLaunchKernelGGL(blur_lines_h_kernel, dim3((unsigned)B * strips), dim3(kLineThreads), lds_h, s, x, tmp_d, H, WC, strips, taps_d, n_taps);
+      bg::launch(blur_lines_h_kernel, dim3((unsigned)B * strips), dim3(kLineThreads), lds_h, s, x, tmp_d, H, WC, strips, taps_d, n_taps);
       int rc = L.done("blur_lines_h_kernel");
       if (rc) return rc;
     }
     const int rows_total = B * H;
     bg::Launch L(stream, "blur_lines_w", flops / 2, bytes);
-    hipLaunchKernelGGL(blur_lines_w_kernel, dim3(bg::cdiv(rows_total, rows_per)), dim3(kLineThreads), lds_w, s, tmp_d, y, rows_total, W, C,
+    bg::launch(blur_lines_w_kernel, dim3(bg::cdiv(rows_total, rows_per)), dim3(kLineThreads), lds_w, s, tmp_d, y, rows_total, W, C,
                        rows_per, taps_d, n_taps);
     return L.done("blur_lines_w_kernel");
   }
   const unsigned grid = (unsigned)std::min<size_t>(bg::cdiv(total, kBlurThreads), 256 * 16);
   {
     bg::Launch L(stream, "blur_pass_h", flops / 2, bytes);
-    hipLaunchKernelGGL(blur_pass_kernel<0>, dim3(grid), dim3(kBlurThreads), 0, s, x, tmp_d, total, H, W, C, taps_d, n_taps);
+    bg::launch(blur_pass_kernel<0>, dim3(grid), dim3(kBlurThreads), 0, s, x, tmp_d, total, H, W, C, taps_d, n_taps);
     int rc = L.done("blur_pass_kernel<H>");
     if (rc) return rc;
   }
   bg::Launch L(stream, "blur_pass_w", flops / 2, bytes);
-  hipLaunchKernelGGL(blur_pass_kernel<1>, dim3(grid), dim3(kBlurThreads), 0, s, tmp_d, y, total, H, W, C, taps_d, n_taps);
+  bg::launch(blur_pass_kernel<1>, dim3(grid), dim3(kBlurThreads), 0, s, tmp_d, y, total, H, W, C, taps_d, n_taps);
   return L.done("blur_pass_kernel<W>");
 }
 

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include "../../include/bgan.h"
+#include "launch.h"
 
 namespace bg {
 
@@ -29,20 +30,27 @@ inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 
 
 inline unsigned cdiv(size_t a, size_t b) { return (unsigned)((a + b - 1) / b); }
 
-// Scoped launch bracket: clears stale errors, records profiling events, checks the launch.
+// Scoped launch bracket: records profiling events, checks the launch.  While a step program is being recorded the bracket
+// leaves its name / flops / bytes in the program as well, so that a replay under bg_prof_enable(1) produces the same records.
 struct Launch {
   hipStream_t s;
-  bool prof;
+  bool prof;          // the launcher should compute its metadata (profiling on, or a program is being recorded)
+  bool live;          // events are recorded around this launch now
+  bool rec;
   Launch(void* stream, const char* name, double flops = 0, double bytes = 0)
-      : s(static_cast<hipStream_t>(stream)), prof(prof_on()) {
-    if (prof) prof_begin(s, name, flops, bytes);
+      : s(static_cast<hipStream_t>(stream)), live(prof_on()), rec(recording()) {
+    prof = live || rec;
+    if (live) prof_begin(s, name, flops, bytes);
+    if (rec) rec_note(1, name, flops, bytes);
   }
   void exec_flops(double f) {
-    if (prof) prof_exec_flops(f);
+    if (live) prof_exec_flops(f);
+    if (rec) rec_note(3, nullptr, f, 0);
   }
   int done(const char* what) {
     hipError_t e = hipGetLastError();
-    if (prof) prof_end(s);
+    if (live) prof_end(s);
+    if (rec) rec_note(2, nullptr, 0, 0);
     if (e != hipSuccess) return fail(BG_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     return BG_OK;
   }

@@ -395,11 +395,11 @@ int try_conv_c16(int bwd_data, const float* a, const float* w, float* c, int B, 
     if (Ws == 64) {
       static bool attr = false;
       if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_dgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
-      hipLaunchKernelGGL((conv_c16_dgrad_kernel<64>), grid, dim3(256), lds, L.s, p);
+      bg::launch((conv_c16_dgrad_kernel<64>), grid, dim3(256), lds, L.s, p);
     } else {
       static bool attr = false;
       if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_dgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
-      hipLaunchKernelGGL((conv_c16_dgrad_kernel<32>), grid, dim3(256), lds, L.s, p);
+      bg::launch((conv_c16_dgrad_kernel<32>), grid, dim3(256), lds, L.s, p);
     }
     *taken = 1;
     return L.done("conv_c16_dgrad_kernel");
@@ -426,8 +426,8 @@ int try_conv_c16(int bwd_data, const float* a, const float* w, float* c, int B, 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       attr = true;
     }
-    if (Wo == 64) hipLaunchKernelGGL((conv_c16_fwd_kernel<64>), grid, dim3(256), lds, L.s, p);
-    else hipLaunchKernelGGL((conv_c16_fwd_kernel<32>), grid, dim3(256), lds, L.s, p);
+    if (Wo == 64) bg::launch((conv_c16_fwd_kernel<64>), grid, dim3(256), lds, L.s, p);
+    else bg::launch((conv_c16_fwd_kernel<32>), grid, dim3(256), lds, L.s, p);
     *taken = 1;
     return L.done("conv_c16_fwd_kernel");
   }

@@ -1016,16 +1016,16 @@ int launch_igemm(GatherParams& p, const bg_epilogue* epi, void* stream, const ch
     bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
     if (L.prof) L.exec_flops(gather_exec_flops(p, BM, BN));
     if constexpr (has_stats_variant) {
-      if (st_ok) hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv, true>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
-      else hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv, false>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
+      if (st_ok) bg::launch((conv_igemm_kernel<BM, BN, BK, WMv, WNv, true>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
+      else bg::launch((conv_igemm_kernel<BM, BN, BK, WMv, WNv, false>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
     } else {
-      hipLaunchKernelGGL((conv_igemm_kernel<BM, BN, BK, WMv, WNv, false>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
+      bg::launch((conv_igemm_kernel<BM, BN, BK, WMv, WNv, false>), grid, dim3(WMv * WNv * 64), 0, L.s, p);
     }
     int rc = L.done(name);
     if (rc || ks == 1) return rc;
   }
   bg::Launch L(stream, "conv_igemm_splitk_reduce", 0, (double)(ks + 1) * total * 4);
-  hipLaunchKernelGGL(igemm_splitk_reduce_kernel, dim3((unsigned)std::min<size_t>(bg::cdiv(total / 4, 256), 2048)), dim3(256), 0, L.s, p, total);
+  bg::launch(igemm_splitk_reduce_kernel, dim3((unsigned)std::min<size_t>(bg::cdiv(total / 4, 256), 2048)), dim3(256), 0, L.s, p, total);
   return L.done("igemm_splitk_reduce_kernel");
 }
 
@@ -1103,7 +1103,7 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
       }
       snprintf(name, sizeof name, "conv_thin_n_mfma_%s", tag);
       bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
-      hipLaunchKernelGGL(conv_thin_n_mfma_kernel, dim3(bg::cdiv(p.Wd, kTnCols), bg::cdiv(p.Hd, kTnRows), p.B), dim3(256), lds, L.s, p, k, pt, pl);
+      bg::launch(conv_thin_n_mfma_kernel, dim3(bg::cdiv(p.Wd, kTnCols), bg::cdiv(p.Hd, kTnRows), p.B), dim3(256), lds, L.s, p, k, pt, pl);
       return L.done(name);
     }
   }
@@ -1137,8 +1137,8 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
       bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
 #define BG_TNP(CKv)                                                                                                        \
   do {                                                                                                                     \
-    if (kThinTW == 16) hipLaunchKernelGGL((conv_thin_n_patch_kernel<CKv, 16>), grid, dim3(256), lds, L.s, p, tiles_x, tiles_y); \
-    else hipLaunchKernelGGL((conv_thin_n_patch_kernel<CKv, 32>), grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);          \
+    if (kThinTW == 16) bg::launch((conv_thin_n_patch_kernel<CKv, 16>), grid, dim3(256), lds, L.s, p, tiles_x, tiles_y); \
+    else bg::launch((conv_thin_n_patch_kernel<CKv, 32>), grid, dim3(256), lds, L.s, p, tiles_x, tiles_y);          \
   } while (0)
       if (p.Ck == 16) BG_TNP(16);
       else if (p.Ck == 32) BG_TNP(32);
@@ -1150,7 +1150,7 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
   if (p.N <= 4 && p.Ck % 4 == 0) {
     snprintf(name, sizeof name, "conv_thin_n_%s", tag);
     bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
-    hipLaunchKernelGGL(conv_thin_n_kernel, dim3(bg::cdiv(Mmax, 256), 1, p.nphase), dim3(256), 0, L.s, p);
+    bg::launch(conv_thin_n_kernel, dim3(bg::cdiv(Mmax, 256), 1, p.nphase), dim3(256), 0, L.s, p);
     return L.done(name);
   }
   if (p.Ck <= 4 && p.N <= 64 && (size_t)p.B * p.nphase <= 65535) {
@@ -1173,20 +1173,20 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
       snprintf(name, sizeof name, "conv_thin_k_mfma_%s", tag);
       dim3 grid(tiles_x, tiles_y, p.B * p.nphase);
       bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
-      if (NT == 1) hipLaunchKernelGGL(conv_thin_k_mfma_kernel<1>, grid, dim3(256), lds, L.s, p);
-      else hipLaunchKernelGGL(conv_thin_k_mfma_kernel<2>, grid, dim3(256), lds, L.s, p);
+      if (NT == 1) bg::launch(conv_thin_k_mfma_kernel<1>, grid, dim3(256), lds, L.s, p);
+      else bg::launch(conv_thin_k_mfma_kernel<2>, grid, dim3(256), lds, L.s, p);
       return L.done(name);
     }
   }
   if (p.Ck <= 4) {
     snprintf(name, sizeof name, "conv_thin_k_%s", tag);
     bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
-    hipLaunchKernelGGL(conv_thin_k_kernel, dim3(bg::cdiv(Mmax, 256), bg::cdiv(p.N, 32), p.nphase), dim3(256), 0, L.s, p);
+    bg::launch(conv_thin_k_kernel, dim3(bg::cdiv(Mmax, 256), bg::cdiv(p.N, 32), p.nphase), dim3(256), 0, L.s, p);
     return L.done(name);
   }
   snprintf(name, sizeof name, "conv_direct_%s", tag);
   bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
-  hipLaunchKernelGGL(conv_direct_kernel, dim3(bg::cdiv((size_t)Mmax * p.N, 256), 1, p.nphase), dim3(256), 0, L.s, p);
+  bg::launch(conv_direct_kernel, dim3(bg::cdiv((size_t)Mmax * p.N, 256), 1, p.nphase), dim3(256), 0, L.s, p);
   return L.done(name);
 }
 
@@ -1258,7 +1258,7 @@ int bg_transpose_last2(const float* src, float* dst, int T, int R, int C, void* 
   BG_REQUIRE(src && dst, BG_ERR_NULL, "bg_transpose_last2: null pointer");
   BG_REQUIRE(T > 0 && R > 0 && C > 0 && T <= 65535, BG_ERR_BAD_SHAPE, "bg_transpose_last2: T=%d R=%d C=%d", T, R, C);
   bg::Launch L(stream, "transpose_last2", 0, 8.0 * T * R * C);
-  hipLaunchKernelGGL(transpose_last2_kernel, dim3(bg::cdiv(C, 32), bg::cdiv(R, 32), T), dim3(256), 0, L.s, src, dst, R, C);
+  bg::launch(transpose_last2_kernel, dim3(bg::cdiv(C, 32), bg::cdiv(R, 32), T), dim3(256), 0, L.s, src, dst, R, C);
   return L.done("transpose_last2_kernel");
 }
 
@@ -1267,7 +1267,7 @@ int bg_transpose_last2_batched(const float* src_base, float* dst_base, const int
   BG_REQUIRE(n > 0 && total_tiles > 0, BG_ERR_BAD_SHAPE, "bg_transpose_last2_batched: n=%d tiles=%d", n, total_tiles);
   BG_REQUIRE(bg::aligned16(src_base) && bg::aligned16(dst_base), BG_ERR_BAD_ALIGNMENT, "bg_transpose_last2_batched: bases must be 16-byte aligned");
   bg::Launch L(stream, "transpose_last2", 0, 0);
-  hipLaunchKernelGGL(transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, L.s, src_base, dst_base,
+  bg::launch(transpose_batched_kernel, dim3((unsigned)total_tiles), dim3(256), 0, L.s, src_base, dst_base,
                      reinterpret_cast<const TransposeDesc*>(desc_d), n);
   return L.done("transpose_batched_kernel");
 }

@@ -280,8 +280,8 @@ template <int K, int S>
 int launch_rows(const RowParams& p, dim3 grid, size_t lds, hipStream_t s) {
   const bool wide = p.Wi == 128;
   const int ep = p.epi_mode == BG_EPI_NONE ? 0 : p.epi_mode == BG_EPI_TANH ? 1 : 2;
-#define BG_RS2(KSv, EPv) do { if (wide) hipLaunchKernelGGL((conv_rows_scatter_kernel<KSv, K, S, 128, EPv>), grid, dim3(512), lds, s, p); \
-                              else hipLaunchKernelGGL((conv_rows_scatter_kernel<KSv, K, S, 64, EPv>), grid, dim3(256), lds, s, p); } while (0)
+#define BG_RS2(KSv, EPv) do { if (wide) bg::launch((conv_rows_scatter_kernel<KSv, K, S, 128, EPv>), grid, dim3(512), lds, s, p); \
+                              else bg::launch((conv_rows_scatter_kernel<KSv, K, S, 64, EPv>), grid, dim3(256), lds, s, p); } while (0)
 #define BG_RS(KSv) do { if (ep == 0) BG_RS2(KSv, 0); else if (ep == 1) BG_RS2(KSv, 1); else BG_RS2(KSv, 2); } while (0)
   switch (p.Ck) {
     case 16: BG_RS(4); return 1;
@@ -442,8 +442,8 @@ template <int K>
 int launch_rows_gather(const RowGParams& p, int tg, dim3 grid, size_t lds, hipStream_t s) {
   const int nt = p.N / 16;
   const bool mask = p.epi_mode == BG_EPI_BIAS_LRELU && p.keep != nullptr;
-#define BG_RG(TGv, NTv) do { if (mask) hipLaunchKernelGGL((conv_rows_gather_kernel<TGv, NTv, K, true>), grid, dim3(256), lds, s, p); \
-                             else hipLaunchKernelGGL((conv_rows_gather_kernel<TGv, NTv, K, false>), grid, dim3(256), lds, s, p); } while (0)
+#define BG_RG(TGv, NTv) do { if (mask) bg::launch((conv_rows_gather_kernel<TGv, NTv, K, true>), grid, dim3(256), lds, s, p); \
+                             else bg::launch((conv_rows_gather_kernel<TGv, NTv, K, false>), grid, dim3(256), lds, s, p); } while (0)
   if (tg == 1) { if (nt == 1) BG_RG(1, 1); else if (nt == 2) BG_RG(1, 2); else BG_RG(1, 4); }
   else if (tg == 2) { if (nt == 1) BG_RG(2, 1); else if (nt == 2) BG_RG(2, 2); else BG_RG(2, 4); }
   else { if (nt == 1) BG_RG(4, 1); else if (nt == 2) BG_RG(4, 2); else BG_RG(4, 4); }

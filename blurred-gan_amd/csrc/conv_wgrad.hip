@@ -1445,7 +1445,7 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
   int rc;
   if (pl.mode == 0) {
     bg::Launch L(stream, "conv_wgrad_direct", flops, 0);
-    hipLaunchKernelGGL(wgrad_direct_kernel, dim3(bg::cdiv(nout, 256), pl.ksplit), dim3(256), 0, L.s, p);
+    bg::launch(wgrad_direct_kernel, dim3(bg::cdiv(nout, 256), pl.ksplit), dim3(256), 0, L.s, p);
     rc = L.done("wgrad_direct_kernel");
   } else if (pl.mode == 32) {
     bg::Launch L(stream, "conv_wgrad_c16", flops, 0);
@@ -1457,8 +1457,8 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_c16_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
       attr = true;
     }
-    if (p.Wo == 64) hipLaunchKernelGGL((conv_wgrad_c16_kernel<64>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nstrips, spi);
-    else hipLaunchKernelGGL((conv_wgrad_c16_kernel<32>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nstrips, spi);
+    if (p.Wo == 64) bg::launch((conv_wgrad_c16_kernel<64>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nstrips, spi);
+    else bg::launch((conv_wgrad_c16_kernel<32>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nstrips, spi);
     rc = L.done("conv_wgrad_c16_kernel");
   } else if (pl.mode == 31) {
     bg::Launch L(stream, "conv_wgrad_mfma_thin_ci", flops, 0);
@@ -1467,7 +1467,7 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     const int nt = Cout / 16;
     const size_t lds = std::max((size_t)((rb - 1) * stride + ksize) * (W * Cin + 2 * kTiHalo), (size_t)ksize * nt * 4 * 64) * sizeof(float);
     BG_REQUIRE(lds <= 64 * 1024, BG_ERR_UNSUPPORTED, "bg_conv2d_bwd_filter: thin-Ci row kernel needs %zu bytes of LDS", lds);
-#define BG_TI(NTv, Kv) hipLaunchKernelGGL((conv_wgrad_thin_ci_kernel<NTv, Kv>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi, rb)
+#define BG_TI(NTv, Kv) bg::launch((conv_wgrad_thin_ci_kernel<NTv, Kv>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi, rb)
     if (ksize == 5) { if (nt == 1) BG_TI(1, 5); else if (nt == 2) BG_TI(2, 5); else BG_TI(4, 5); }
     else { if (nt == 1) BG_TI(1, 3); else if (nt == 2) BG_TI(2, 3); else BG_TI(4, 3); }
 #undef BG_TI
@@ -1478,10 +1478,10 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     const int mt = Cin / 16;
     const size_t lds = std::max((size_t)(kTcRows + ksize - 1) * (W * Cout + 2 * kTcHalo), (size_t)4 * ksize * mt * 4 * 64) * sizeof(float);
     BG_REQUIRE(lds <= 64 * 1024, BG_ERR_UNSUPPORTED, "bg_conv2d_bwd_filter: thin-Co row kernel needs %zu bytes of LDS", lds);
-    if (ksize == 5 && mt == 2) hipLaunchKernelGGL((conv_wgrad_thin_co_kernel<2, 5>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
-    else if (ksize == 5) hipLaunchKernelGGL((conv_wgrad_thin_co_kernel<1, 5>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
-    else if (mt == 2) hipLaunchKernelGGL((conv_wgrad_thin_co_kernel<2, 3>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
-    else hipLaunchKernelGGL((conv_wgrad_thin_co_kernel<1, 3>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
+    if (ksize == 5 && mt == 2) bg::launch((conv_wgrad_thin_co_kernel<2, 5>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
+    else if (ksize == 5) bg::launch((conv_wgrad_thin_co_kernel<1, 5>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
+    else if (mt == 2) bg::launch((conv_wgrad_thin_co_kernel<2, 3>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
+    else bg::launch((conv_wgrad_thin_co_kernel<1, 3>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nblocks, bpi);
     rc = L.done("conv_wgrad_thin_co_kernel");
   } else {
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.taps_in_grid == 1 ? ksize * ksize : (pl.taps_in_grid == 2 ? ksize : 1), pl.ksplit);
@@ -1490,9 +1490,9 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     switch (pl.mode) {
 #define BG_V3(BMv, BNv, BKv, WMv, WNv, WKv)                                                                               \
   do {                                                                                                                   \
-    if (p.pow2 == 2) hipLaunchKernelGGL((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, 2>), grid1, dim3(256), 0, L.s, p);     \
-    else if (p.pow2 == 1) hipLaunchKernelGGL((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, 1>), grid1, dim3(256), 0, L.s, p); \
-    else hipLaunchKernelGGL((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, 0>), grid1, dim3(256), 0, L.s, p);        \
+    if (p.pow2 == 2) bg::launch((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, 2>), grid1, dim3(256), 0, L.s, p);     \
+    else if (p.pow2 == 1) bg::launch((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, 1>), grid1, dim3(256), 0, L.s, p); \
+    else bg::launch((conv_wgrad_v3_kernel<BMv, BNv, BKv, WMv, WNv, WKv, 0>), grid1, dim3(256), 0, L.s, p);        \
   } while (0)
       case 1: BG_V3(128, 128, 32, 2, 2, 1); break;
       case 2: BG_V3(64, 64, 32, 2, 2, 1); break;
@@ -1500,14 +1500,14 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
       case 4: BG_V3(32, 64, 64, 1, 2, 2); break;
       case 5: BG_V3(32, 32, 128, 1, 1, 4); break;
 #undef BG_V3
-      case 6: hipLaunchKernelGGL((conv_wgrad_tg_kernel<5, 64, 2, 2>), grid1, dim3(256), 0, L.s, p); break;
-      case 7: hipLaunchKernelGGL((conv_wgrad_tg_kernel<5, 32, 1, 4>), grid1, dim3(256), 0, L.s, p); break;
-      case 10: hipLaunchKernelGGL((conv_wgrad_kernel<32, 64, 64, 1, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
-      case 11: hipLaunchKernelGGL((conv_wgrad_kernel<96, 32, 64, 1, 1, 4, 1>), grid, dim3(256), 0, L.s, p); break;
-      case 12: hipLaunchKernelGGL((conv_wgrad_kernel<128, 32, 64, 1, 1, 4, 1>), grid, dim3(256), 0, L.s, p); break;
-      case 20: hipLaunchKernelGGL((conv_wgrad_kernel<64, 32, 64, 2, 1, 2, 2>), grid, dim3(256), 0, L.s, p); break;
-      case 21: hipLaunchKernelGGL((conv_wgrad_kernel<32, 96, 64, 1, 1, 4, 2>), grid, dim3(256), 0, L.s, p); break;
-      default: hipLaunchKernelGGL((conv_wgrad_kernel<32, 128, 64, 1, 1, 4, 2>), grid, dim3(256), 0, L.s, p); break;
+      case 6: bg::launch((conv_wgrad_tg_kernel<5, 64, 2, 2>), grid1, dim3(256), 0, L.s, p); break;
+      case 7: bg::launch((conv_wgrad_tg_kernel<5, 32, 1, 4>), grid1, dim3(256), 0, L.s, p); break;
+      case 10: bg::launch((conv_wgrad_kernel<32, 64, 64, 1, 2, 2, 1>), grid, dim3(256), 0, L.s, p); break;
+      case 11: bg::launch((conv_wgrad_kernel<96, 32, 64, 1, 1, 4, 1>), grid, dim3(256), 0, L.s, p); break;
+      case 12: bg::launch((conv_wgrad_kernel<128, 32, 64, 1, 1, 4, 1>), grid, dim3(256), 0, L.s, p); break;
+      case 20: bg::launch((conv_wgrad_kernel<64, 32, 64, 2, 1, 2, 2>), grid, dim3(256), 0, L.s, p); break;
+      case 21: bg::launch((conv_wgrad_kernel<32, 96, 64, 1, 1, 4, 2>), grid, dim3(256), 0, L.s, p); break;
+      default: bg::launch((conv_wgrad_kernel<32, 128, 64, 1, 1, 4, 2>), grid, dim3(256), 0, L.s, p); break;
     }
     rc = L.done("conv_wgrad_kernel");
   }
@@ -1515,13 +1515,13 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
   if (pl.ksplit > 1) {
     bg::Launch L(stream, "conv_wgrad_reduce", 0, (double)(pl.ksplit + 1) * nout * 4);
     if (nout % 4 == 0 && bg::aligned16(ws_d) && pl.ksplit >= 64 && nout <= 65536)
-      hipLaunchKernelGGL(wgrad_reduce_tall_kernel, dim3(bg::cdiv(nout / 4, 16)), dim3(1024), 0, L.s, static_cast<const float*>(ws_d), dw,
+      bg::launch(wgrad_reduce_tall_kernel, dim3(bg::cdiv(nout / 4, 16)), dim3(1024), 0, L.s, static_cast<const float*>(ws_d), dw,
                          (int)nout, pl.ksplit, beta, scale);
     else if (nout % 4 == 0 && bg::aligned16(ws_d))
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(bg::cdiv(nout / 4, 64)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,
+      bg::launch(wgrad_reduce_kernel, dim3(bg::cdiv(nout / 4, 64)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,
                          (int)nout, pl.ksplit, beta, scale);
     else
-      hipLaunchKernelGGL(wgrad_reduce_scalar_kernel, dim3(bg::cdiv(nout, 256)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,
+      bg::launch(wgrad_reduce_scalar_kernel, dim3(bg::cdiv(nout, 256)), dim3(256), 0, L.s, static_cast<const float*>(ws_d), dw,
                          (int)nout, pl.ksplit, beta, scale);
     rc = L.done("wgrad_reduce_kernel");
   }

@@ -531,6 +531,20 @@ __global__ __launch_bounds__(kT) void fill_kernel(float* x, float v, size_t n) {
   for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < n; e += (size_t)gridDim.x * kT) x[e] = v;
 }
 
+// dst = src; float4 body when both are 16-byte aligned, scalar tail / fallback otherwise
+__global__ __launch_bounds__(kT) void copy_kernel(float* __restrict__ dst, const float* __restrict__ src, size_t n, int vec) {
+  const size_t tid = (size_t)blockIdx.x * kT + threadIdx.x, nth = (size_t)gridDim.x * kT;
+  size_t done = 0;
+  if (vec) {
+    const size_t n4 = n / 4;
+    const float4* s4 = reinterpret_cast<const float4*>(src);
+    float4* d4 = reinterpret_cast<float4*>(dst);
+    for (size_t e = tid; e < n4; e += nth) d4[e] = s4[e];
+    done = n4 * 4;
+  }
+  for (size_t e = done + tid; e < n; e += nth) dst[e] = src[e];
+}
+
 __global__ __launch_bounds__(kT) void scale_kernel(float* x, float v, size_t n) {
   for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < n; e += (size_t)gridDim.x * kT) x[e] *= v;
 }
@@ -686,21 +700,21 @@ int bg_gemm_f32(const float* A, const float* Bm, float* C, int M, int N, int K, 
   const double flops = 2.0 * M * (double)N * K;
   if (N == 1 && !transA && K >= 64) {
     bg::Launch L(stream, "dense_rowdot", flops, 4.0 * M * K);
-    hipLaunchKernelGGL(rowdot_kernel, dim3(M), dim3(kT), 0, L.s, A, Bm, C, M, K, bias, beta, scale);
+    bg::launch(rowdot_kernel, dim3(M), dim3(kT), 0, L.s, A, Bm, C, M, K, bias, beta, scale);
     return L.done("rowdot_kernel");
   }
   if (N == 1 && transA && K >= 64) {
     bg::Launch L(stream, "dense_gemv_t", flops, 4.0 * M * K);
-    hipLaunchKernelGGL(gemv_t_kernel, dim3(bg::cdiv(M, 64)), dim3(1024), 0, L.s, A, Bm, C, M, K, bias, beta, scale);
+    bg::launch(gemv_t_kernel, dim3(bg::cdiv(M, 64)), dim3(1024), 0, L.s, A, Bm, C, M, K, bias, beta, scale);
     return L.done("gemv_t_kernel");
   }
   if ((size_t)M * N >= 4096 && K >= 8) {
     bg::Launch L(stream, "dense_gemm_tiled", flops, 0);
-    hipLaunchKernelGGL(gemm_tiled_kernel, dim3(bg::cdiv(N, 64), bg::cdiv(M, 64)), dim3(kT), 0, L.s, A, Bm, C, M, N, K, transA, transB, bias, beta, scale);
+    bg::launch(gemm_tiled_kernel, dim3(bg::cdiv(N, 64), bg::cdiv(M, 64)), dim3(kT), 0, L.s, A, Bm, C, M, N, K, transA, transB, bias, beta, scale);
     return L.done("gemm_tiled_kernel");
   }
   bg::Launch L(stream, "dense_gemm", flops, 0);
-  hipLaunchKernelGGL(gemm_naive_kernel, dim3(grid_for((size_t)M * N)), dim3(kT), 0, L.s, A, Bm, C, M, N, K, transA, transB, bias, beta, scale);
+  bg::launch(gemm_naive_kernel, dim3(grid_for((size_t)M * N)), dim3(kT), 0, L.s, A, Bm, C, M, N, K, transA, transB, bias, beta, scale);
   return L.done("gemm_naive_kernel");
 }
 
@@ -718,13 +732,13 @@ int bg_colsum_f32(const float* x, float* out, int M, int N, int square, float be
   float* partial = static_cast<float*>(ws_d);
   {
     bg::Launch L(stream, "colsum_partial", 0, 4.0 * M * N);
-    if (flat_ok(M, N) && bg::aligned16(x)) hipLaunchKernelGGL(colsum_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, x, M, N, square, partial);
-    else hipLaunchKernelGGL(colsum_partial_kernel, dim3(nblk, bg::cdiv(N, 64)), dim3(kT), 0, L.s, x, M, N, square, partial);
+    if (flat_ok(M, N) && bg::aligned16(x)) bg::launch(colsum_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, x, M, N, square, partial);
+    else bg::launch(colsum_partial_kernel, dim3(nblk, bg::cdiv(N, 64)), dim3(kT), 0, L.s, x, M, N, square, partial);
     int rc = L.done("colsum_partial_kernel");
     if (rc) return rc;
   }
   bg::Launch L(stream, "colsum_final", 0, 0);
-  hipLaunchKernelGGL(colsum_final_kernel, dim3(bg::cdiv(N, kT / 64)), dim3(kT), 0, L.s, partial, nblk, N, out, beta, scale);
+  bg::launch(colsum_final_kernel, dim3(bg::cdiv(N, kT / 64)), dim3(kT), 0, L.s, partial, nblk, N, out, beta, scale);
   return L.done("colsum_final_kernel");
 }
 
@@ -742,20 +756,20 @@ int bg_bn_train_fwd(const float* x, float* y, int M, int C, const float* gamma, 
   const size_t total = (size_t)M * C;
   {
     bg::Launch L(stream, "bn_stats_partial", 0, 4.0 * total);
-    if (flat_ok(M, C) && bg::aligned16(x)) hipLaunchKernelGGL(bn_stats_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, x, M, C, partial);
-    else hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, x, M, C, partial);
+    if (flat_ok(M, C) && bg::aligned16(x)) bg::launch(bn_stats_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, x, M, C, partial);
+    else bg::launch(bn_stats_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, x, M, C, partial);
     int rc = L.done("bn_stats_partial_kernel");
     if (rc) return rc;
   }
   {
     bg::Launch L(stream, "bn_stats_final", 0, 0);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, nblk, M, C, save_mean, save_inv,
+    bg::launch(bn_stats_final_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, nblk, M, C, save_mean, save_inv,
                        moving_mean, moving_var, eps, momentum, unbiased);
     int rc = L.done("bn_stats_final_kernel");
     if (rc) return rc;
   }
   bg::Launch L(stream, "bn_apply_lrelu", 0, 8.0 * total);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, save_mean, save_inv, 0, eps,
+  bg::launch(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, save_mean, save_inv, 0, eps,
                      lrelu_alpha);
   return L.done("bn_apply_kernel");
 }
@@ -769,13 +783,13 @@ int bg_bn_train_fwd_partials(const float* partial_d, int nrows, const float* x, 
   const size_t total = (size_t)M * C;
   {
     bg::Launch L(stream, "bn_stats_final", 0, 0);
-    hipLaunchKernelGGL(bn_stats_final_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial_d, nrows, M, C, save_mean, save_inv,
+    bg::launch(bn_stats_final_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial_d, nrows, M, C, save_mean, save_inv,
                        moving_mean, moving_var, eps, momentum, unbiased);
     int rc = L.done("bn_stats_final_kernel");
     if (rc) return rc;
   }
   bg::Launch L(stream, "bn_apply_lrelu", 0, 8.0 * total);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, save_mean, save_inv, 0, eps,
+  bg::launch(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, save_mean, save_inv, 0, eps,
                      lrelu_alpha);
   return L.done("bn_apply_kernel");
 }
@@ -784,7 +798,7 @@ int bg_bn_sums_from_partials(const float* partial_d, int nrows, int C, float* su
   BG_REQUIRE(partial_d && sums_d, BG_ERR_NULL, "bg_bn_sums_from_partials: null pointer");
   BG_REQUIRE(C > 0 && nrows > 0, BG_ERR_BAD_SHAPE, "bg_bn_sums_from_partials: C=%d nrows=%d", C, nrows);
   bg::Launch L(stream, "bn_stats_final", 0, 0);
-  hipLaunchKernelGGL(partials_to_sums_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial_d, nrows, C, sums_d);
+  bg::launch(partials_to_sums_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial_d, nrows, C, sums_d);
   return L.done("partials_to_sums_kernel");
 }
 
@@ -794,7 +808,7 @@ int bg_bn_infer_fwd(const float* x, float* y, int M, int C, const float* gamma, 
   BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_infer_fwd: M=%d C=%d", M, C);
   const size_t total = (size_t)M * C;
   bg::Launch L(stream, "bn_apply_lrelu", 0, 8.0 * total);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, moving_mean, moving_var, 1,
+  bg::launch(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, moving_mean, moving_var, 1,
                      eps, lrelu_alpha);
   return L.done("bn_apply_kernel");
 }
@@ -811,21 +825,21 @@ int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, 
   {
     bg::Launch L(stream, "bn_bwd_partial", 0, 12.0 * total);
     if (flat_ok(M, C) && bg::aligned16(dy) && bg::aligned16(y) && bg::aligned16(x) && bg::aligned16(save_mean) && bg::aligned16(save_inv))
-      hipLaunchKernelGGL(bn_bwd_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv, lrelu_alpha, partial);
+      bg::launch(bn_bwd_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv, lrelu_alpha, partial);
     else
-      hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv,
+      bg::launch(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv,
                          lrelu_alpha, partial);
     int rc = L.done("bn_bwd_partial_kernel");
     if (rc) return rc;
   }
   {
     bg::Launch L(stream, "bn_bwd_final", 0, 0);
-    hipLaunchKernelGGL(bn_bwd_final_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, nblk, C, dgamma, dbeta);
+    bg::launch(bn_bwd_final_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, nblk, C, dgamma, dbeta);
     int rc = L.done("bn_bwd_final_kernel");
     if (rc) return rc;
   }
   bg::Launch L(stream, "bn_bwd_apply", 0, 16.0 * total);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M, C, gamma, save_mean, save_inv,
+  bg::launch(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M, C, gamma, save_mean, save_inv,
                      dgamma, dbeta, lrelu_alpha);
   return L.done("bn_bwd_apply_kernel");
 }
@@ -835,15 +849,15 @@ int bg_bn_fold_f32(const float* gamma, const float* beta, const float* moving_me
   BG_REQUIRE(gamma && beta && moving_mean && moving_var && scale_out && shift_out, BG_ERR_NULL, "bg_bn_fold_f32: null pointer");
   BG_REQUIRE(C > 0, BG_ERR_BAD_SHAPE, "bg_bn_fold_f32: C=%d", C);
   bg::Launch L(stream, "bn_fold", 0, 0);
-  hipLaunchKernelGGL(bn_fold_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, gamma, beta, moving_mean, moving_var, eps, C, scale_out, shift_out);
+  bg::launch(bn_fold_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, gamma, beta, moving_mean, moving_var, eps, C, scale_out, shift_out);
   return L.done("bn_fold_kernel");
 }
 
 static int bn_partials(const char* fn, const float* x, int M, int C, float* partial, void* stream) {
   const int nblk = red_blocks(M, C);
   bg::Launch L(stream, "bn_stats_partial", 0, 4.0 * M * C);
-  if (flat_ok(M, C) && bg::aligned16(x)) hipLaunchKernelGGL(bn_stats_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, x, M, C, partial);
-  else hipLaunchKernelGGL(bn_stats_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, x, M, C, partial);
+  if (flat_ok(M, C) && bg::aligned16(x)) bg::launch(bn_stats_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, x, M, C, partial);
+  else bg::launch(bn_stats_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, x, M, C, partial);
   return L.done(fn);
 }
 
@@ -855,7 +869,7 @@ int bg_bn_stats_f32(const float* x, int M, int C, float* sums_d, void* ws_d, siz
   int rc = bn_partials("bn_stats_partial_kernel", x, M, C, partial, stream);
   if (rc) return rc;
   bg::Launch L(stream, "bn_partials_to_sums", 0, 0);
-  hipLaunchKernelGGL(partials_to_sums_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, red_blocks(M, C), C, sums_d);
+  bg::launch(partials_to_sums_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, red_blocks(M, C), C, sums_d);
   return L.done("partials_to_sums_kernel");
 }
 
@@ -865,7 +879,7 @@ int bg_bn_finalize_f32(const float* sums_d, int M_total, int C, float* save_mean
   BG_REQUIRE((moving_mean == nullptr) == (moving_var == nullptr), BG_ERR_NULL, "bg_bn_finalize_f32: moving_mean/var must both be given or both NULL");
   BG_REQUIRE(M_total > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_finalize_f32: M_total=%d C=%d", M_total, C);
   bg::Launch L(stream, "bn_finalize", 0, 0);
-  hipLaunchKernelGGL(bn_finalize_sums_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, sums_d, M_total, C, save_mean, save_inv, moving_mean,
+  bg::launch(bn_finalize_sums_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, sums_d, M_total, C, save_mean, save_inv, moving_mean,
                      moving_var, eps, momentum, unbiased);
   return L.done("bn_finalize_sums_kernel");
 }
@@ -876,7 +890,7 @@ int bg_bn_apply_f32(const float* x, float* y, int M, int C, const float* gamma, 
   BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_apply_f32: M=%d C=%d", M, C);
   const size_t total = (size_t)M * C;
   bg::Launch L(stream, "bn_apply_lrelu", 0, 8.0 * total);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, mean, inv, 0, 0.f, lrelu_alpha);
+  bg::launch(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, mean, inv, 0, 0.f, lrelu_alpha);
   return L.done("bn_apply_kernel");
 }
 
@@ -890,15 +904,15 @@ int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, 
   {
     bg::Launch L(stream, "bn_bwd_partial", 0, 12.0 * M * C);
     if (flat_ok(M, C) && bg::aligned16(dy) && bg::aligned16(y) && bg::aligned16(x) && bg::aligned16(save_mean) && bg::aligned16(save_inv))
-      hipLaunchKernelGGL(bn_bwd_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv, lrelu_alpha, partial);
+      bg::launch(bn_bwd_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv, lrelu_alpha, partial);
     else
-      hipLaunchKernelGGL(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv,
+      bg::launch(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv,
                          lrelu_alpha, partial);
     int rc = L.done("bn_bwd_partial_kernel");
     if (rc) return rc;
   }
   bg::Launch L(stream, "bn_partials_to_sums", 0, 0);
-  hipLaunchKernelGGL(partials_to_sums_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, nblk, C, sums_d);
+  bg::launch(partials_to_sums_kernel, dim3(bg::cdiv(C, kT / 64)), dim3(kT), 0, L.s, partial, nblk, C, sums_d);
   return L.done("partials_to_sums_kernel");
 }
 
@@ -908,7 +922,7 @@ int bg_bn_bwd_apply_f32(const float* dy, const float* y, const float* x, float* 
   BG_REQUIRE(M > 0 && M_total >= M && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_bwd_apply_f32: M=%d M_total=%d C=%d", M, M_total, C);
   const size_t total = (size_t)M * C;
   bg::Launch L(stream, "bn_bwd_apply", 0, 16.0 * total);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M_total, C, gamma, save_mean, save_inv,
+  bg::launch(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M_total, C, gamma, save_mean, save_inv,
                      sums_d + C /* dgamma = sum dz*xhat */, sums_d /* dbeta = sum dz */, lrelu_alpha);
   return L.done("bn_bwd_apply_kernel");
 }
@@ -917,7 +931,7 @@ int bg_bn_param_grads_f32(const float* sums_d, int C, float scale, float* dgamma
   BG_REQUIRE(sums_d && dgamma && dbeta, BG_ERR_NULL, "bg_bn_param_grads_f32: null pointer");
   BG_REQUIRE(C > 0, BG_ERR_BAD_SHAPE, "bg_bn_param_grads_f32: C=%d", C);
   bg::Launch L(stream, "bn_param_grads", 0, 0);
-  hipLaunchKernelGGL(bn_param_grads_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, sums_d, C, scale, dgamma, dbeta);
+  bg::launch(bn_param_grads_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, sums_d, C, scale, dgamma, dbeta);
   return L.done("bn_param_grads_kernel");
 }
 
@@ -925,14 +939,14 @@ int bg_lerp_f32(const float* r, const float* f, const float* alpha_b, float* xha
   BG_POINTWISE_PROLOGUE("bg_lerp_f32", r && f && alpha_b && xhat, (long)B * n_per);
   const size_t total = (size_t)B * n_per;
   bg::Launch L(stream, "lerp", 0, 12.0 * total);
-  hipLaunchKernelGGL(lerp_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, r, f, alpha_b, xhat, total, n_per);
+  bg::launch(lerp_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, r, f, alpha_b, xhat, total, n_per);
   return L.done("lerp_kernel");
 }
 
 int bg_row_norm_f32(const float* g, float* norm_b, int B, int n_per, void* stream) {
   BG_POINTWISE_PROLOGUE("bg_row_norm_f32", g && norm_b, (long)B * n_per);
   bg::Launch L(stream, "row_norm", 0, 4.0 * B * n_per);
-  hipLaunchKernelGGL(row_norm_kernel, dim3(B), dim3(1024), 0, L.s, g, norm_b, n_per);
+  bg::launch(row_norm_kernel, dim3(B), dim3(1024), 0, L.s, g, norm_b, n_per);
   return L.done("row_norm_kernel");
 }
 
@@ -940,7 +954,7 @@ int bg_gp_seed_f32(const float* g, const float* norm_b, float coef, float* out, 
   BG_POINTWISE_PROLOGUE("bg_gp_seed_f32", g && norm_b && out, (long)B * n_per);
   const size_t total = (size_t)B * n_per;
   bg::Launch L(stream, "gp_seed", 0, 8.0 * total);
-  hipLaunchKernelGGL(gp_seed_kernel<false>, dim3(grid_for(total)), dim3(kT), 0, L.s, g, norm_b, coef, out, total, n_per);
+  bg::launch(gp_seed_kernel<false>, dim3(grid_for(total)), dim3(kT), 0, L.s, g, norm_b, coef, out, total, n_per);
   return L.done("gp_seed_kernel");
 }
 
@@ -948,7 +962,7 @@ int bg_gp_seed_guarded_f32(const float* g, const float* norm_b, float coef, floa
   BG_POINTWISE_PROLOGUE("bg_gp_seed_guarded_f32", g && norm_b && out, (long)B * n_per);
   const size_t total = (size_t)B * n_per;
   bg::Launch L(stream, "gp_seed", 0, 8.0 * total);
-  hipLaunchKernelGGL(gp_seed_kernel<true>, dim3(grid_for(total)), dim3(kT), 0, L.s, g, norm_b, coef, out, total, n_per);
+  bg::launch(gp_seed_kernel<true>, dim3(grid_for(total)), dim3(kT), 0, L.s, g, norm_b, coef, out, total, n_per);
   return L.done("gp_seed_kernel");
 }
 
@@ -956,14 +970,14 @@ int bg_mul_grad_f32(const float* d, const float* ref, const uint8_t* keep, float
                     void* stream) {
   BG_POINTWISE_PROLOGUE("bg_mul_grad_f32", d && ref && out, n);
   bg::Launch L(stream, "mul_grad", 0, 12.0 * n);
-  hipLaunchKernelGGL(mul_grad_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, d, ref, keep, alpha, scale, out, n);
+  bg::launch(mul_grad_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, d, ref, keep, alpha, scale, out, n);
   return L.done("mul_grad_kernel");
 }
 
 int bg_tanh_bwd_f32(const float* dy, const float* y, float* out, size_t n, void* stream) {
   BG_POINTWISE_PROLOGUE("bg_tanh_bwd_f32", dy && y && out, n);
   bg::Launch L(stream, "tanh_bwd", 0, 12.0 * n);
-  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, dy, y, out, n);
+  bg::launch(tanh_bwd_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, dy, y, out, n);
   return L.done("tanh_bwd_kernel");
 }
 
@@ -971,21 +985,29 @@ int bg_outer_f32(const float* s_b, const float* w_k, float* out, int B, int K, v
   BG_POINTWISE_PROLOGUE("bg_outer_f32", s_b && w_k && out, (long)B * K);
   const size_t total = (size_t)B * K;
   bg::Launch L(stream, "outer", 0, 4.0 * total);
-  hipLaunchKernelGGL(outer_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, s_b, w_k, out, total, K);
+  bg::launch(outer_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, s_b, w_k, out, total, K);
   return L.done("outer_kernel");
 }
 
 int bg_fill_f32(float* x, float v, size_t n, void* stream) {
   BG_POINTWISE_PROLOGUE("bg_fill_f32", x, n);
   bg::Launch L(stream, "fill", 0, 4.0 * n);
-  hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, x, v, n);
+  bg::launch(fill_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, x, v, n);
   return L.done("fill_kernel");
+}
+
+int bg_copy_f32(float* dst, const float* src, size_t n, void* stream) {
+  BG_POINTWISE_PROLOGUE("bg_copy_f32", dst && src, n);
+  bg::Launch L(stream, "copy", 0, 8.0 * n);
+  const int vec = bg::aligned16(dst) && bg::aligned16(src);
+  bg::launch(copy_kernel, dim3(grid_for(n, vec ? 4 : 1)), dim3(kT), 0, L.s, dst, src, n, vec);
+  return L.done("copy_kernel");
 }
 
 int bg_scale_f32(float* x, float v, size_t n, void* stream) {
   BG_POINTWISE_PROLOGUE("bg_scale_f32", x, n);
   bg::Launch L(stream, "scale", 0, 8.0 * n);
-  hipLaunchKernelGGL(scale_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, x, v, n);
+  bg::launch(scale_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, x, v, n);
   return L.done("scale_kernel");
 }
 
@@ -993,14 +1015,14 @@ int bg_wgangp_d_loss(const float* fs, const float* rs, const float* norm_b, int 
                      float vec_scale, float* dfs, float* drs, float* metrics_d, void* stream) {
   BG_POINTWISE_PROLOGUE("bg_wgangp_d_loss", fs && rs && dfs && drs && metrics_d, B);
   bg::Launch L(stream, "d_loss", 0, 0);
-  hipLaunchKernelGGL(d_loss_kernel, dim3(1), dim3(kT), 0, L.s, fs, rs, norm_b, B, inv_gbs, gp_coef, e_drift, vec_scale, dfs, drs, metrics_d);
+  bg::launch(d_loss_kernel, dim3(1), dim3(kT), 0, L.s, fs, rs, norm_b, B, inv_gbs, gp_coef, e_drift, vec_scale, dfs, drs, metrics_d);
   return L.done("d_loss_kernel");
 }
 
 int bg_wgan_g_loss(const float* s, int B, float inv_gbs, float* ds, float* metrics_d, void* stream) {
   BG_POINTWISE_PROLOGUE("bg_wgan_g_loss", s && ds && metrics_d, B);
   bg::Launch L(stream, "g_loss", 0, 0);
-  hipLaunchKernelGGL(g_loss_kernel, dim3(1), dim3(kT), 0, L.s, s, B, inv_gbs, ds, metrics_d);
+  bg::launch(g_loss_kernel, dim3(1), dim3(kT), 0, L.s, s, B, inv_gbs, ds, metrics_d);
   return L.done("g_loss_kernel");
 }
 
@@ -1009,7 +1031,7 @@ int bg_u8_normalize_resize_f32(const uint8_t* src, float* dst, int B, int Hs, in
   BG_REQUIRE(B > 0 && Hs > 0 && Ws > 0 && C > 0 && Hd > 0 && Wd > 0, BG_ERR_BAD_SHAPE, "bg_u8_normalize_resize_f32: B=%d %dx%dx%d -> %dx%d", B, Hs, Ws, C, Hd, Wd);
   const size_t total = (size_t)B * Hd * Wd * C;
   bg::Launch L(stream, "u8_normalize_resize", 0, (double)B * Hs * Ws * C + 4.0 * total);
-  hipLaunchKernelGGL(u8_normalize_resize_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, src, dst, total, Hs, Ws, C, Hd, Wd,
+  bg::launch(u8_normalize_resize_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, src, dst, total, Hs, Ws, C, Hd, Wd,
                      (float)Hs / (float)Hd, (float)Ws / (float)Wd);
   return L.done("u8_normalize_resize_kernel");
 }
@@ -1018,14 +1040,18 @@ int bg_adam_f32(float* theta, float* m, float* v, const float* g, size_t n, floa
                 void* stream) {
   BG_POINTWISE_PROLOGUE("bg_adam_f32", theta && m && v && g, n);
   bg::Launch L(stream, "adam", 0, 28.0 * n);
-  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, theta, m, v, g, n, lr_t, b1, b2, eps);
+  const int slot = bg::take_bind(BG_BIND_ADAM_LR);        // step program: lr_t re-read from a slot before every replay
+  bg::launch(adam_kernel, dim3(grid_for(n)), dim3(kT), 0, L.s, theta, m, v, g, n, lr_t, b1, b2, eps);
+  bg::bind_last(5, bg::BIND_F32_FROM_F64, slot);
   return L.done("adam_kernel");
 }
 
 int bg_uniform_f32(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream) {
   BG_POINTWISE_PROLOGUE("bg_uniform_f32", out, n);
   bg::Launch L(stream, "rng_uniform", 0, 4.0 * n);
-  hipLaunchKernelGGL(uniform_kernel, dim3(grid_for(n, 4)), dim3(kT), 0, L.s, out, n, seed, offset);
+  const int slot = bg::take_bind(BG_BIND_RNG_OFFSET);     // step program: the counter offset advances per replay
+  bg::launch(uniform_kernel, dim3(grid_for(n, 4)), dim3(kT), 0, L.s, out, n, seed, offset);
+  bg::bind_last(3, bg::BIND_U64, slot);
   return L.done("uniform_kernel");
 }
 
@@ -1033,7 +1059,9 @@ int bg_keep_mask_u8(uint8_t* out, size_t n, float keep_prob, uint64_t seed, uint
   BG_POINTWISE_PROLOGUE("bg_keep_mask_u8", out, n);
   BG_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, BG_ERR_BAD_SHAPE, "bg_keep_mask_u8: keep_prob=%g", keep_prob);
   bg::Launch L(stream, "rng_keep_mask", 0, 1.0 * n);
-  hipLaunchKernelGGL(keep_mask_kernel, dim3(grid_for(n, 4)), dim3(kT), 0, L.s, out, n, keep_prob, seed, offset);
+  const int slot = bg::take_bind(BG_BIND_RNG_OFFSET);
+  bg::launch(keep_mask_kernel, dim3(grid_for(n, 4)), dim3(kT), 0, L.s, out, n, keep_prob, seed, offset);
+  bg::bind_last(4, bg::BIND_U64, slot);
   return L.done("keep_mask_kernel");
 }
 

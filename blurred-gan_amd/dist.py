@@ -67,13 +67,79 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # BGAN_DIST_BACKEND=gloo: rehearsal of the multi-rank path where RCCL cannot run (several ranks on one card)
     backend = backend or os.environ.get("BGAN_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
-    td.init_process_group(backend=backend)
+    kw = {}
+    if use_cuda and backend == "nccl":
+        # bind the communicator to this rank's card up front: no "guessing device ID based on global rank" (and no hang when
+        # the rank -> GPU mapping is not the identity)
+        kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+    td.init_process_group(backend=backend, **kw)
+    _check_one_device_per_rank(backend)
     return world_size()
+
+
+def _device_identity():
+    """(host, physical card) of this process's current device: uuid where the runtime reports one, else PCI domain:bus:device."""
+    import socket
+    pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+    uuid = getattr(pr, "uuid", None)
+    pci = ":".join(str(getattr(pr, a, "?")) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    return f"{socket.gethostname()}|{uuid if uuid is not None else ''}|{pci}"
+
+
+def _distinct_devices(ids):
+    """ids: one identity string per rank.  Raises when two ranks resolved to the same physical card."""
+    seen = {}
+    for r, ident in enumerate(ids):
+        if ident in seen:
+            raise RuntimeError(f"ranks {seen[ident]} and {r} both run on device {ident}: RCCL ranks sharing a card hang in their "
+                               "first collective.  Launch one process per GPU, or give every rank its own device mask "
+                               "(ROCR_VISIBLE_DEVICES); to rehearse several ranks on one card use BGAN_DIST_BACKEND=gloo")
+        seen[ident] = r
+
+
+def _check_one_device_per_rank(backend):
+    """After set_device and BEFORE the first collective: every rank publishes (host, card) through the rendezvous store (TCP,
+    no GPU involved) and reads everybody else's.  A per-rank mask and a box-wide mask look the same to local_rank(); this is
+    where the second case -- two ranks silently on one card -- turns into an error instead of a hang."""
+    if backend != "nccl" and os.environ.get("BGAN_DIST_CHECK_DEVICES") != "1":
+        return
+    store = td.distributed_c10d._get_default_store()
+    me, n = td.get_rank(), td.get_world_size()
+    store.set(f"bgan_device_of_rank_{me}", _device_identity())
+    ids = [store.get(f"bgan_device_of_rank_{r}").decode() for r in range(n)]
+    _distinct_devices(ids)
 
 
 class _Done:
     def wait(self):
         return None
+
+
+class _RecordedWork:
+    """A collective issued while a step program is being recorded (program.Recorder): issuing it and waiting for it become
+    host actions of the program, re-run at the same points of every replay."""
+
+    def __init__(self, rec, issue):
+        self._rec, self._issue = rec, issue
+        self._cur = issue()
+        rec.host_action(self._reissue)
+
+    def _reissue(self):
+        self._cur = self._issue()
+
+    def _rewait(self):
+        self._cur.wait()
+
+    def wait(self):
+        self._cur.wait()
+        from . import program
+        if program._active is self._rec:
+            self._rec.host_action(self._rewait)
+
+
+def _recorder():
+    from . import program
+    return program._active
 
 
 def all_reduce_sum_async(flat):
@@ -82,6 +148,13 @@ def all_reduce_sum_async(flat):
     backward statistics travel while the layer above computes its filter gradient).  No-op for a single replica."""
     if not collectives_active():
         return _Done()
+    rec = _recorder()
+    if rec is not None:
+        return _RecordedWork(rec, lambda: _all_reduce_sum_async(flat))
+    return _all_reduce_sum_async(flat)
+
+
+def _all_reduce_sum_async(flat):
     if _use_abi_comm(flat):
         return AbiComm.get().all_reduce_async(flat)
     if flat.is_cuda and td.get_backend() == "gloo":      # CPU-side rehearsal: stage through the host, synchronous
@@ -99,13 +172,21 @@ def all_reduce_sum_(flat):
     (``async_op=False``) collective on the caller's current stream."""
     if not collectives_active():
         return flat
-    if _use_abi_comm(flat):
+    rec = _recorder()
+    if rec is not None:
+        rec.host_action(lambda: _all_reduce_sum_inline(flat))
+    _all_reduce_sum_inline(flat)
+    return flat
+
+
+def _all_reduce_sum_inline(flat):
+    inline = os.environ.get("BGAN_DP_INLINE_SYNC", "1") != "0"      # 0: back on the collective stream with event hops (both routes)
+    if _use_abi_comm(flat) and inline:
         AbiComm.get().all_reduce_inline(flat)
-    elif flat.is_cuda and td.get_backend() != "gloo" and os.environ.get("BGAN_DP_INLINE_SYNC", "1") != "0":
+    elif flat.is_cuda and td.get_backend() != "gloo" and inline and not _use_abi_comm(flat):
         td.all_reduce(flat, op=td.ReduceOp.SUM, async_op=False)
     else:
-        all_reduce_sum_async(flat).wait()
-    return flat
+        _all_reduce_sum_async(flat).wait()
 
 
 class AbiComm:
@@ -200,6 +281,9 @@ class GradReducer:
         seg = self.flat[lo:hi]
         self.n_collectives += 1
         from . import ops
+        rec = _recorder()
+        if rec is not None:      # step program: this bucket goes out at the same point of every replay
+            rec.host_action(lambda: self._issue_seg(seg))
         with ops.trace_range("all_reduce"):
             self._issue_seg(seg)
         self.covered.append((lo, hi))
@@ -254,6 +338,12 @@ class GradReducer:
             pos = max(pos, hi)
         if pos < self.n:
             self._issue(pos, self.n)
+        rec = _recorder()
+        if rec is not None:
+            rec.host_action(self._wait_all)
+        self._wait_all()
+
+    def _wait_all(self):
         for w in self.works:
             w.wait()
         self.works = []

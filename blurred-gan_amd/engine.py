@@ -204,37 +204,46 @@ class Net:
         self.store.refresh_transposed(self.conv_layers)
 
     def blur_taps(self, H, W):
+        """(device buffer, tap count) of the layer's CURRENT std for H x W images (gaussian_blur.py:21-31,83-88 through
+        bg_blur_policy / bg_gauss_kernel_1d).  The taps of one image size live in ONE persistent device buffer whose address never
+        changes (a recorded step program holds it); when std has changed since the last call the new weights are copied into it
+        in stream order.  sigma changes every batch under BlurDecayController: the upload goes through a pinned staging ring and
+        an asynchronous copy (a pageable copy would wait for the stream to drain)."""
         std = float(self.blur.std)
-        key = (std, H, W)
-        hit = self._taps_cache.get(key)
-        if hit is None:
+        ent = self._taps_cache.get((H, W))
+        if ent is None:
+            ent = self._taps_cache[(H, W)] = {"std": None, "nt": 0, "dev": torch.zeros(1024, dtype=torch.float32, device=self.device)}
+        if ent["std"] != std:
             ks, se, nt = ops.blur_policy(std, H, W)
             taps = ops.gauss_kernel_1d(se, ks)
             assert len(taps) == nt
-            # sigma changes every batch under BlurDecayController: upload without stalling the host (a pageable copy waits
-            # for the stream to drain and the GPU then idles until the host has caught up) -- pinned staging ring, async copy
+            if nt > 1024:
+                raise NotImplementedError(f"blur with {nt} taps (> 1024)")
             ring = self.__dict__.setdefault("_taps_ring", {"i": 0, "bufs": [], "evs": []})
             if not ring["bufs"]:
                 for _ in range(8):
-                    ring["bufs"].append(torch.empty(1024, dtype=torch.float32, pin_memory=True))
+                    ring["bufs"].append(torch.empty(1024, dtype=torch.float32, pin_memory=self.device.type == "cuda"))
                     ring["evs"].append(None)
             i = ring["i"] = (ring["i"] + 1) % len(ring["bufs"])
             if ring["evs"][i] is not None:
                 ring["evs"][i].synchronize()                  # slot re-used 8 uploads later: normally long complete
-            if nt <= 1024:
-                host = ring["bufs"][i][:nt]
-                host.copy_(torch.tensor(taps, dtype=torch.float32))
-                t = torch.empty(nt, dtype=torch.float32, device=self.device)
-                t.copy_(host, non_blocking=True)
+            host = ring["bufs"][i][:nt]
+            host.copy_(torch.tensor(taps, dtype=torch.float32))
+            ent["dev"][:nt].copy_(host, non_blocking=True)
+            if self.device.type == "cuda":
                 ev = torch.cuda.Event()
                 ev.record()
                 ring["evs"][i] = ev
-            else:
-                t = torch.tensor(taps, dtype=torch.float32, device=self.device)
-            if len(self._taps_cache) > 64:
-                self._taps_cache.clear()
-            hit = self._taps_cache[key] = (t, nt)
-        return hit
+            ent["std"], ent["nt"] = std, nt
+        return ent["dev"], ent["nt"]
+
+    def blur_n_taps(self, H=None, W=None):
+        """Tap count of the current std (uploads the taps if std changed): part of a step program's key."""
+        if self.blur is None:
+            return 0
+        H = self.in_shape[0] if H is None else H
+        W = self.in_shape[1] if W is None else W
+        return self.blur_taps(H, W)[1]
 
     def apply_blur(self, x, y):
         """y = blur(x) with the layer's current std (blurred_gan.py:30; self-adjoint, so also its backward)."""
@@ -268,15 +277,14 @@ class Net:
             o = 0
             for t in inputs:
                 n = int(t.shape[0])
-                ctx.a0[o:o + n].copy_(t.view(n, *self.in_shape))
+                ops.copy_(ctx.a0[o:o + n], t.view(n, *self.in_shape).contiguous())
                 o += n
             x = ctx.a0
         ctx.dropout_active = bool(training)
         mi = 0
         drawn = False
         if training and masks is None and ctx.keep_rate is not None and ctx.keep_total:
-            ops.keep_mask(ctx.keep_flat[:ctx.keep_total], 1.0 - ctx.keep_rate, seed, self.rng_offset)
-            self.rng_offset += (ctx.keep_total + 3) // 4
+            ops.keep_mask(ctx.keep_flat[:ctx.keep_total], 1.0 - ctx.keep_rate, seed, counter=(self, "rng_offset"))
             drawn = True
         for i, st in enumerate(self.stages):
             xin = x.view(B, *st.in_shape)
@@ -291,8 +299,7 @@ class Net:
                     if masks is not None:
                         keep.copy_(masks[mi].view(keep.shape))
                     elif not drawn:
-                        ops.keep_mask(keep, 1.0 - st.drop, seed, self.rng_offset)
-                        self.rng_offset += (keep.numel() + 3) // 4
+                        ops.keep_mask(keep, 1.0 - st.drop, seed, counter=(self, "rng_offset"))
                 mi += 1
             stat_rows = 0          # rows of BatchNorm statistics partials the conv left behind (0: none)
             if st.kind == "dense":
@@ -401,8 +408,8 @@ class Net:
                 M = gv.numel() // C
                 dz = ctx.buf(ctx.dz, i)
                 ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
-                dg = st_.grad_of(st.bn, "gamma") if need_dw else torch.empty(C, device=self.device)
-                db = st_.grad_of(st.bn, "beta") if need_dw else torch.empty(C, device=self.device)
+                dg = st_.grad_of(st.bn, "gamma") if need_dw else ctx.bn_sums(("dgamma_scratch", i), C)[:C]
+                db = st_.grad_of(st.bn, "beta") if need_dw else ctx.bn_sums(("dbeta_scratch", i), C)[:C]
                 if sync_bn:
                     world = dist.world_size()
                     sums = ctx.bn_sums(i, C)

@@ -7,7 +7,7 @@ import ctypes as C
 
 import torch
 
-from . import _lib
+from . import _lib, program
 from ._lib import Epilogue, EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_AFFINE_LRELU, check
 
 LRELU_ALPHA = 0.3
@@ -47,6 +47,8 @@ def _ptr(t):
         _dev_index = cur
     if not t.is_contiguous():
         raise ValueError("tensor must be contiguous")
+    if program._active is not None:
+        program._active.keep.append(t)      # a step program holds this address: the tensor lives as long as the program
     return t.data_ptr()                # a plain int (c_void_p parameter): one Python object less per operand and launch
 
 
@@ -325,6 +327,14 @@ def scale_(x, v):
     return x
 
 
+def copy_(dst, src):
+    """dst <- src through a kernel of the library (recordable into a step program)."""
+    _f32(dst, src)
+    assert dst.numel() == src.numel()
+    check(_lib.load().bg_copy_f32(_ptr(dst), _ptr(src), dst.numel(), _stream()), "bg_copy_f32")
+    return dst
+
+
 def wgangp_d_loss(fs, rs, norm_b, inv_gbs, gp_coef, e_drift, vec_scale, dfs, drs, metrics):
     B = fs.numel()
     check(_lib.load().bg_wgangp_d_loss(_ptr(fs), _ptr(rs), _ptr(norm_b), B, inv_gbs, gp_coef, e_drift, vec_scale, _ptr(dfs),
@@ -350,13 +360,29 @@ def adam(theta, m, v, g, lr_t, b1=0.9, b2=0.999, eps=1e-7):
     check(_lib.load().bg_adam_f32(_ptr(theta), _ptr(m), _ptr(v), _ptr(g), theta.numel(), lr_t, b1, b2, eps, _stream()), "bg_adam_f32")
 
 
-def uniform(out, seed, offset=0):
+def _draw_offset(out, offset, counter):
+    """Offset of a counter-based draw.  ``counter`` = (obj, attr): the draw starts at that host counter, which then advances by the
+    Philox blocks the draw consumes; while a step program is being recorded the launch's offset is bound to the counter."""
+    if counter is None:
+        return offset
+    obj, attr = counter
+    inc = (out.numel() + 3) // 4
+    offset = getattr(obj, attr)
+    if program._active is not None:
+        program._active.bind_rng(obj, attr, inc)        # the recorded launch re-reads the counter before every replay
+    setattr(obj, attr, offset + inc)
+    return offset
+
+
+def uniform(out, seed, offset=0, counter=None):
+    offset = _draw_offset(out, offset, counter)
     check(_lib.load().bg_uniform_f32(_ptr(out), out.numel(), seed, offset, _stream()), "bg_uniform_f32")
     return out
 
 
-def keep_mask(out, keep_prob, seed, offset=0):
+def keep_mask(out, keep_prob, seed, offset=0, counter=None):
     assert out.dtype == torch.uint8
+    offset = _draw_offset(out, offset, counter)
     check(_lib.load().bg_keep_mask_u8(_ptr(out), out.numel(), keep_prob, seed, offset, _stream()), "bg_keep_mask_u8")
     return out
 

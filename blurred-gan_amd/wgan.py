@@ -15,7 +15,7 @@ from typing import List
 import numpy as np
 import torch
 
-from . import dist, ops
+from . import dist, ops, program
 from .gaussian_blur import Variable
 from .layers import Sequential, get_seed
 from .utils import JsonSerializable, ParseableFromCommandLine
@@ -62,6 +62,8 @@ class _Adam:
         self.iterations += 1
         t = self.iterations
         lr_t = float(self.learning_rate) * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
+        if program._active is not None:        # step program: the recorded launch takes lr_t of the NEXT iteration from a slot
+            program._active.bind_adam(self, ADAM_B1, ADAM_B2)
         ops.adam(store.theta[:store.n_train], store.m[:store.n_train], store.v[:store.n_train],
                  store.grad[:store.n_train], lr_t, ADAM_B1, ADAM_B2, ADAM_EPS)
         store.tr_dirty = True
@@ -104,7 +106,7 @@ class WGAN:
     def __init__(self, generator: Sequential, discriminator: Sequential, hyperparams: "WGAN.HyperParameters",
                  config: TrainingConfig, *args, reproduce_vector_loss_quirk: bool = True, sync_metrics: bool = True,
                  sync_batchnorm: bool = True, merge_critic_passes: bool = True, gp_zero_norm_guard: bool = False,
-                 merge_gp_filter_gradients: bool = True, **kwargs):
+                 merge_gp_filter_gradients: bool = True, step_replay: bool = True, **kwargs):
         self.hparams = hyperparams
         if dist.world_size() > 1 and int(hyperparams.global_batch_size) != int(hyperparams.batch_size) * dist.world_size():
             import warnings
@@ -153,6 +155,11 @@ class WGAN:
         # a sample whose critic input-gradient is exactly zero makes the penalty's second-order seed (n-1)/n * g = NaN, in the
         # reference too (tf.norm's gradient at 0); True takes the subgradient 0 for that sample instead
         self.gp_zero_norm_guard = gp_zero_norm_guard
+        # train_on_batch records the launch list of its discriminator_step / generator_step once and replays it with one call
+        # into the library (program.py, include/bgan.h bg_dstep / bg_gstep); False or BGAN_NO_STEP_REPLAY=1: every step eager
+        self.step_replay = step_replay and program.enabled_by_env()
+        self._programs = program.StepPrograms()
+        self._reals_stage = None
         self._rng_seed = get_seed()
         self._rng_off = 0
         self._bufs = {}
@@ -189,8 +196,7 @@ class WGAN:
     def _uniform(self, name, shape):
         """tf.random.uniform stand-in (wgan.py:118,237): own counter-based stream, seed + rank."""
         out = self._buf(name, shape)
-        ops.uniform(out, self._rng_seed + 7919 * dist.rank(), self._rng_off)
-        self._rng_off += (out.numel() + 3) // 4
+        ops.uniform(out, self._rng_seed + 7919 * dist.rank(), counter=(self, "_rng_off"))
         return out
 
     def _inj(self, key):
@@ -210,13 +216,28 @@ class WGAN:
         self.batch_size = int(reals.shape[0])
         self._injected = randomness
         self._defer_metrics = True
+        replay = self.step_replay and randomness is None and self._replayable()
         try:
-            with ops.trace_range("d_step"):
-                disc_loss, self.images = self.discriminator_step(reals)
-            g_ran = int(self.n_batches) % self.d_steps_per_g_step == 0
-            if g_ran:
-                with ops.trace_range("g_step"):
-                    self.generator_step()
+            if replay:
+                # a recorded program holds device addresses: the batch goes through ONE persistent staging buffer
+                reals = self._stage_reals(reals)
+                stream = ops._stream()
+                with ops.trace_range("d_step"):
+                    disc_loss, self.images = self._programs.run(self._step_key("d", reals), lambda: self.discriminator_step(reals),
+                                                                stream, self._exit_state)
+                    if self._programs.last_was_replay:
+                        self._after_d_step()
+                g_ran = int(self.n_batches) % self.d_steps_per_g_step == 0
+                if g_ran:
+                    with ops.trace_range("g_step"):
+                        self._programs.run(self._step_key("g", reals), self.generator_step, stream, self._exit_state)
+            else:
+                with ops.trace_range("d_step"):
+                    disc_loss, self.images = self.discriminator_step(reals)
+                g_ran = int(self.n_batches) % self.d_steps_per_g_step == 0
+                if g_ran:
+                    with ops.trace_range("g_step"):
+                        self.generator_step()
         finally:
             self._injected = None
             self._defer_metrics = False
@@ -229,6 +250,34 @@ class WGAN:
         self.n_img.assign_add(self.batch_size)
         self.n_batches.assign_add(1)
         return self._organize_metrics()
+
+    def _after_d_step(self):
+        """Host-side bookkeeping of discriminator_step that a replayed step program has to repeat (subclasses)."""
+
+    # ---- step programs (program.py)
+    def _replayable(self):
+        G, D = self.generator.net(), self.discriminator.net()
+        return self.device.type == "cuda" and G.capture_branches is None and D.capture_branches is None
+
+    def _stage_reals(self, reals):
+        st = self._reals_stage
+        if st is None or st.shape != reals.shape:
+            st = self._reals_stage = torch.empty_like(reals)
+        if st.data_ptr() != reals.data_ptr():
+            st.copy_(reals, non_blocking=True)
+        return st
+
+    def _step_key(self, kind, reals):
+        """Everything that shapes the launch list of a step or is baked into its kernel arguments."""
+        G, D = self.generator.net(), self.discriminator.net()
+        hp = tuple(sorted((k, v) for k, v in vars(self.hparams).items() if isinstance(v, (int, float, str, bool))))
+        return (kind, tuple(reals.shape), D.blur_n_taps(), G.store.tr_dirty, D.store.tr_dirty, self.merge_critic_passes,
+                self.merge_gp_filter_gradients, self.sync_batchnorm, self.gp_zero_norm_guard, self.reproduce_vector_loss_quirk,
+                self.sync_metrics, dist.collectives_active(), dist.world_size(), G.fuse_bn_stats, D.fuse_bn_stats, hp)
+
+    def _exit_state(self):
+        G, D = self.generator.net(), self.discriminator.net()
+        return [(G.store, "tr_dirty", G.store.tr_dirty), (D.store, "tr_dirty", D.store.tr_dirty)]
 
     def _metrics_dev(self):
         return self._buf("step_metrics", (16,))

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BG_ABI_VERSION 3
+#define BG_ABI_VERSION 4
 
 typedef enum {
   BG_OK = 0,
@@ -212,6 +212,9 @@ int bg_tanh_bwd_f32(const float* dy, const float* y, float* out, size_t n, void*
 int bg_outer_f32(const float* s_b, const float* w_k, float* out, int B, int K, void* stream);
 int bg_fill_f32(float* x, float v, size_t n, void* stream);
 int bg_scale_f32(float* x, float v, size_t n, void* stream);
+/* dst[0:n] = src[0:n] as a KERNEL (a blur-less critic's [fakes; reals; x-hat] batch is assembled with it: a launch that a step
+   program records like any other, which a runtime memcpy would not be) */
+int bg_copy_f32(float* dst, const float* src, size_t n, void* stream);
 
 /* ---- losses (wgan.py:128-130,155-157,272-285) ----------------------------------------------- */
 /* From scores fs[B], rs[B] and the per-sample norms n[B] of the GP gradient:
@@ -237,6 +240,44 @@ int bg_adam_f32(float* theta, float* m, float* v, const float* g, size_t n, floa
 /* ---- RNG: tf.random.uniform (wgan.py:118,237) and Dropout masks; counter-based, own stream ---- */
 int bg_uniform_f32(float* out, size_t n, uint64_t seed, uint64_t offset, void* stream);
 int bg_keep_mask_u8(uint8_t* out, size_t n, float keep_prob, uint64_t seed, uint64_t offset, void* stream);
+
+/* ---- step programs: the step-level entry points of SURVEY.md 8b (bg_dstep / bg_gstep) -----------------------------------
+ * The reference runs one Python pass over its TF ops per batch (wgan.py:86-114: discriminator_step :132-151, generator_step
+ * :159-172).  With static shapes and caller-owned persistent buffers the launch list of such a step is the same every batch, so
+ * it is recorded ONCE and replayed with ONE call:
+ *   bg_program_record_begin(p); ...the entry points above, exactly as the eager step calls them...; bg_program_record_end(p);
+ * While recording, every kernel launch of the calling thread is executed AND appended to `p` as (kernel, grid, block, LDS bytes,
+ * a by-value copy of every kernel argument).  bg_program_replay(p, first, last, stream) issues nodes [first, last) (last < 0 =
+ * all) on `stream` -- no geometry checks, tap tables, grid planning or host language in between.  What changes per step:
+ *   - Adam's lr_t and the RNG counter offsets: announce bg_program_bind_next(what, slot) right before the call that owns the
+ *     argument; the recorded launch then re-reads slots_f64[slot] (BG_BIND_ADAM_LR) / slots_u64[slot] (BG_BIND_RNG_OFFSET) before
+ *     every replay.  The slot arrays belong to the program and are written directly by the host.
+ *   - the blur taps' VALUES live in a caller-owned device buffer the host refreshes in stream order; a changed tap COUNT selects
+ *     other kernels and needs a newly recorded program (the host keeps one per count).
+ *   - collectives (data parallel) are the host's: it splits the replay at the node indices bg_program_size() returned when the
+ *     collective was issued during recording.
+ * Every device pointer seen while recording must stay valid for the life of the program (the host keeps the tensors alive).
+ * bg_dstep / bg_gstep replay a whole program: one call per discriminator_step / generator_step.
+ * bg_program_graph_launch: the same node range as one hipGraph (kernel nodes in a linear chain, bound arguments refreshed with
+ * hipGraphExecKernelNodeSetParams); with bg_prof_enable(1) it falls back to the node-by-node replay.
+ * Profiling brackets travel with the program: a replay under bg_prof_enable(1) yields the same records as the eager step. */
+typedef struct bg_program bg_program;
+#define BG_BIND_ADAM_LR 1     /* bg_adam_f32: lr_t <- (float) slots_f64[slot]                         */
+#define BG_BIND_RNG_OFFSET 2  /* bg_uniform_f32, bg_keep_mask_u8: offset <- slots_u64[slot]            */
+int bg_program_create(bg_program** out, int n_slots);
+int bg_program_destroy(bg_program* p);
+int bg_program_record_begin(bg_program* p);
+int bg_program_record_end(bg_program* p);
+int bg_program_size(const bg_program* p);       /* nodes so far (launches + profiling brackets): replay range boundaries */
+int bg_program_launches(const bg_program* p);   /* kernel launches recorded                                               */
+int bg_program_binds(const bg_program* p);      /* bound arguments recorded                                               */
+int bg_program_bind_next(int what, int slot);
+double* bg_program_slots_f64(bg_program* p);
+uint64_t* bg_program_slots_u64(bg_program* p);
+int bg_program_replay(bg_program* p, int first, int last, void* stream);
+int bg_program_graph_launch(bg_program* p, int first, int last, void* stream);
+int bg_dstep(bg_program* p, void* stream);      /* wgan.py:132-151 as recorded */
+int bg_gstep(bg_program* p, void* stream);      /* wgan.py:159-172 as recorded */
 
 /* ---- data-parallel exchange step (the reference never ran multi-GPU, demo_mnist.py:116) --------
  * One process per GPU.  Rank 0 makes an id and hands its BG_COMM_ID_BYTES bytes to the other ranks over the host's
