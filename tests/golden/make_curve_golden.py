@@ -44,8 +44,30 @@ def swd_value(fakes, reals, seed):
     return float(res[-1])
 
 
-def run(seed, data, hp_extra=None, vector_quirk=True, log=None):
+def run(seed, data, hp_extra=None, vector_quirk=True, log=None, lrelu_alpha=None, sigma=None, tag="ok"):
+    cache = os.path.join(os.environ.get("CURVE_CACHE", "/tmp/curve"), f"run_{tag}_{seed}.npz")
+    if os.path.exists(cache):
+        z = np.load(cache)
+        return {m: z[f"win_{m}"] for m in METRICS}, z["swd"], {m: z[f"step_{m}"] for m in METRICS}
+    out = _run(seed, data, hp_extra, vector_quirk, log, lrelu_alpha, sigma)
+    os.makedirs(os.path.dirname(cache), exist_ok=True)
+    np.savez(cache, swd=out[1], **{f"win_{m}": out[0][m] for m in METRICS}, **{f"step_{m}": out[2][m] for m in METRICS})
+    return out
+
+
+def _run(seed, data, hp_extra, vector_quirk, log, lrelu_alpha, sigma):
+    from oracle import np_ops as O
     torch.manual_seed(seed)
+    saved_alpha = O.LRELU_ALPHA
+    if lrelu_alpha is not None:
+        O.LRELU_ALPHA = lrelu_alpha
+    try:
+        return _run_inner(seed, data, hp_extra, vector_quirk, log, sigma)
+    finally:
+        O.LRELU_ALPHA = saved_alpha
+
+
+def _run_inner(seed, data, hp_extra, vector_quirk, log, sigma):
     hp = dict(global_batch_size=BATCH)
     hp.update(hp_extra or {})
     tr = TR.TorchTrainer(ARCH, seed=seed, std=SD.sigma_schedule(0), hp=hp)
@@ -63,7 +85,7 @@ def run(seed, data, hp_extra=None, vector_quirk=True, log=None):
         TR.discriminator_step_grads = scalar_loss
     try:
         for step, reals in enumerate(SD.batches(data, BATCH, STEPS, seed + 2)):
-            tr.std = SD.sigma_schedule(step)
+            tr.std = SD.sigma_schedule(step) if sigma is None else sigma
             met = tr.train_on_batch(torch.from_numpy(reals), tr.draw(BATCH, gen))
             met["fake_scores"] = 0.5 * (met["fake_scores"] + met["fake_scores_g"])        # Q6
             for m in METRICS:

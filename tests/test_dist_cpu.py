@@ -87,3 +87,75 @@ def test_single_process_dist_helpers_are_noops():
     red.ready(0, 2)
     red.finish()
     assert red.n_collectives == 0 and dist.max_over_ranks(1.5) == 1.5
+
+
+def test_two_ranks_on_one_physical_device_are_refused_not_hung():
+    """a box-wide device mask and a per-rank mask look the same to local_rank(); what tells them apart is the
+    identity of the card each rank ended up on, exchanged through the rendezvous store before the first collective."""
+    from blurred_gan_amd import dist
+    dist._distinct_devices(["hostA|uuid-1|0:1:0", "hostA|uuid-2|0:2:0", "hostB|uuid-1|0:1:0"])       # same card id on another host: fine
+    with pytest.raises(RuntimeError, match="ranks 0 and 2 both run on device"):
+        dist._distinct_devices(["hostA|uuid-1|0:1:0", "hostA|uuid-2|0:2:0", "hostA|uuid-1|0:1:0"])
+
+
+def _same_device_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                      BGAN_DIST_CHECK_DEVICES="1")
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from blurred_gan_amd import dist
+    dist._device_identity = lambda: "thishost|the-one-card|0:5:0"        # an identical mask for both local ranks
+    try:
+        dist.init_from_env(backend="gloo")
+        msg = "no error"
+    except RuntimeError as e:
+        msg = str(e)
+    open(os.path.join(out_dir, f"msg_{rank}.txt"), "w").write(msg)
+    if torch.distributed.is_initialized():
+        torch.distributed.destroy_process_group()
+
+
+def test_identical_device_mask_for_two_local_ranks_raises_on_every_rank(tmp_path):
+    mp.spawn(_same_device_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert "both run on device thishost|the-one-card" in open(tmp_path / f"msg_{r}.txt").read()
+
+
+def test_step_program_api_without_a_gpu():
+    """include/bgan.h bg_program_*: argument checking and the recorder's host-action bookkeeping need no device."""
+    import ctypes as C
+    from blurred_gan_amd import _lib, program
+    lib = _lib.load()
+    h = C.c_void_p()
+    assert lib.bg_program_create(None, 4) == -6 and lib.bg_program_create(C.byref(h), -1) == -1
+    assert lib.bg_program_create(C.byref(h), 4) == 0
+    assert lib.bg_program_bind_next(_lib.BIND_ADAM_LR, 0) == -3               # nothing is being recorded
+    assert lib.bg_program_record_begin(h) == 0
+    assert lib.bg_program_record_begin(h) == -3                                # one recording per thread
+    assert lib.bg_program_replay(h, 0, -1, None) == -3                         # still recording
+    assert lib.bg_program_bind_next(99, 0) == -1 and lib.bg_program_bind_next(_lib.BIND_ADAM_LR, 4) == -1
+    assert lib.bg_program_bind_next(_lib.BIND_RNG_OFFSET, 3) == 0
+    assert lib.bg_program_record_end(h) == -3                                  # a binding no launch consumed
+    assert b"no launch consumed" in lib.bg_last_error()
+    assert lib.bg_program_record_begin(h) == 0 and lib.bg_program_record_end(h) == 0
+    assert lib.bg_program_size(h) == 0 and lib.bg_program_launches(h) == 0 and lib.bg_program_binds(h) == 0
+    assert lib.bg_program_replay(h, 0, -1, None) == 0 and lib.bg_dstep(h, None) == 0 and lib.bg_gstep(h, None) == 0
+    assert lib.bg_program_replay(h, 1, 0, None) == -1 and lib.bg_program_replay(None, 0, -1, None) == -6
+    assert lib.bg_program_destroy(h) == 0 and lib.bg_program_destroy(None) == 0
+    # host actions and per-replay updates run in recording order around the (here empty) stretches of launches
+    log = []
+    rec = program.Recorder()
+    with rec:
+        rec.host_action(lambda: log.append("a"))
+        rec.updates.append(lambda: log.append("u"))
+        rec.host_action(lambda: log.append("b"))
+        rec.result = "r"
+    assert program.active() is None and rec.n_launches == 0
+    assert rec.replay(None) == "r" and log == ["u", "a", "b"]
+    progs = program.StepPrograms(capacity=2)
+    calls = []
+    for _ in range(3):
+        progs.run("k", lambda: calls.append(1) or "x", None)
+    assert calls == [1, 1] and progs.stats == {"eager": 1, "recorded": 1, "replayed": 1} and progs.last_was_replay
+    progs.run("k2", lambda: None, None); progs.run("k3", lambda: None, None)
+    assert list(progs.entries) == ["k2", "k3"]                                 # least recently used program dropped

@@ -263,3 +263,58 @@ def test_bench_two_ranks_strong_scaling_smoke():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_batch"] == 16 and out["value"] > 0
     assert out["config"]["parallelism"] == "dp2" and "8/GPU" in out["config"]["workload"]
+
+
+def _replay_worker(rank, world, port, out_dir, backend, replay, tag):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    if world == 1:
+        os.environ["BGAN_DP_FORCE_COLLECTIVES"] = "1"
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import blurred_gan_amd as bg
+    from blurred_gan_amd import dist, models
+    torch.cuda.set_device(0)
+    torch.distributed.init_process_group(backend=backend)
+    assert dist.collectives_active()
+    arch, B = "mnist", 4
+    bg.set_seed(17)
+    gen, disc = models.DCGANGenerator(arch=arch), models.DCGANDiscriminator(arch=arch)
+    hp = bg.BlurredWGANGP.HyperParameters(initial_blur_std=1.30, global_batch_size=B * world, batch_size=B)
+    gan = bg.BlurredWGANGP(gen, disc, hp, bg.TrainingConfig(log_dir="/tmp/bg_dp_logs"), step_replay=replay)
+    g = torch.Generator().manual_seed(40 + rank)
+    mets = []
+    for i in range(6):
+        gan.std.assign(1.30 - 0.01 * i)                      # 9 taps throughout: one D and one G program
+        mets.append(gan.train_on_batch((torch.rand(B, 28, 28, 1, generator=g) * 2 - 1).cuda()))
+    torch.cuda.synchronize()
+    st = gan._programs.stats
+    assert (st["replayed"] >= 6) if replay else (st["replayed"] == 0), st
+    if replay:       # the collectives of the recorded steps are host actions of their programs
+        assert all(len(e.actions) >= 2 for e in gan._programs.entries.values() if hasattr(e, "actions"))
+    for name, net in (("d", gan.discriminator), ("g", gan.generator)):
+        s = net.store
+        np.save(os.path.join(out_dir, f"{tag}_{name}_theta_{rank}.npy"), s.theta.cpu().numpy())
+        np.save(os.path.join(out_dir, f"{tag}_{name}_state_{rank}.npy"), s.state.cpu().numpy())
+        np.save(os.path.join(out_dir, f"{tag}_{name}_v_{rank}.npy"), s.v.cpu().numpy())
+    np.save(os.path.join(out_dir, f"{tag}_metrics_{rank}.npy"), np.asarray(mets, np.float64))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize("backend,world", [("gloo", 2), ("nccl", 1)])
+def test_replayed_steps_issue_the_same_collectives_as_eager_steps(tmp_path, backend, world):
+    """Step programs under data parallelism (include/bgan.h: collectives are the host's, the replay is split where they were
+    issued while recording): six steps of the MNIST stack with the build's own RNG and a changing sigma, as two gloo ranks on
+    the box's one card and as a ONE-rank RCCL group with every collective forced (bucketed asynchronous gradient all-reduces,
+    SyncBN exchanges in the forward and, overlapped, in the backward, wait-before-Adam) -- replay on against replay off:
+    weights, BatchNorm statistics, Adam's second moments and every step's metrics bit-identical, replicas in lock step."""
+    for replay, tag in ((False, "eager"), (True, "replay")):
+        mp.spawn(_replay_worker, args=(world, _free_port(), str(tmp_path), backend, replay, tag), nprocs=world, join=True)
+    for r in range(world):
+        for name in ("d", "g"):
+            for what in ("theta", "state", "v"):
+                a, b = np.load(tmp_path / f"eager_{name}_{what}_{r}.npy"), np.load(tmp_path / f"replay_{name}_{what}_{r}.npy")
+                np.testing.assert_array_equal(a, b)
+                if r:
+                    np.testing.assert_array_equal(b, np.load(tmp_path / f"replay_{name}_{what}_0.npy"))
+        np.testing.assert_array_equal(np.load(tmp_path / f"eager_metrics_{r}.npy"), np.load(tmp_path / f"replay_metrics_{r}.npy"))
