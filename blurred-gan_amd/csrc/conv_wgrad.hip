@@ -11,6 +11,9 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <mutex>
+#include <type_traits>
+#include <utility>
 
 namespace {
 
@@ -1156,6 +1159,268 @@ __global__ __launch_bounds__(256) void conv_wgrad_c16_kernel(const WgradParams p
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------------
+// Strip-resident filter gradient: 5x5, stride 2, even H / W, Ci a multiple of 32, Co a multiple of 64, Wo = 8 / 16 / 32 -- the
+// critic's inner convs and the generator's inner transposed convs (demo_celeba.py:62-87,104-119) on maps of 16 ... 64 pixels.
+//   dW[kh][kw][ci][co] = sum_{b, oy, ox} x[b, 2oy + kh - 1, 2ox + kw - 1, ci] * dy[b, oy, ox, co]
+// The per-tap kernel above re-reads x AND dy from L2 once per tap (25 x) and issues one 1-KiB vector-memory instruction per
+// 2.7 ... 8 MFMAs on the 32- and 64-channel layers; every such instruction costs the SIMD's matrix pipe ~58 cycles.  Here a
+// STRIP of 64 output pixels (R = 64 / Wo whole output rows of one image) is staged in LDS once -- the 2R + 3 input rows of a
+// 32-channel slice with a zero halo column on each side, and the strip's dy rows of a 64-channel slice -- and serves all 25 taps:
+// the tap shift is an LDS address (an immediate), one vector-memory instruction per ~90 MFMAs.  A workgroup = one (32 ci x 64 co)
+// channel tile and a contiguous range of strips; its 4 waves = (tap half) x (co half), each with 13 accumulator tiles of 32 x 32:
+// 12 taps of its own and the 25th tap, which the two halves share pair by pair (12.5 taps' worth of MFMAs each); LDS is double-buffered and the
+// next strip is loaded in pieces BETWEEN the k-steps of the current one (a few registers in flight, none held across a strip).
+// One partial slab per workgroup -> wgrad_reduce_* (fixed order: deterministic).
+// ------------------------------------------------------------------------------------------------------------------------
+template <int LGWO>
+struct StripGeom {
+  static constexpr int WO = 1 << LGWO, W = 2 * WO, R = 64 / WO, RX = 2 * R + 3, WP = W + 3;
+  static constexpr int XROW = WP * 32, XBUF = RX * XROW, YBUF = 64 * 64, BUF = XBUF + YBUF;
+  static constexpr int NX = RX * W * 8, NLX = (NX + 255) / 256, NL = NLX + 4;      // float4 loads per thread and strip: x, then dy
+  static constexpr size_t lds_bytes = (size_t)2 * BUF * sizeof(float);
+};
+
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+
+// Ordered building blocks of the strip kernel's k loop: volatile asm statements keep their program order, so the LDS reads sit
+// exactly where they are written -- between the MFMAs (left to itself the scheduler sinks every read burst to just in front of
+// its first use and the matrix pipe waits out an LDS round trip per pair; sched_group_barrier patterns made it worse).
+template <int O0>
+__device__ inline void strip_read2(floatx2& dst, unsigned addr) {      // dwords at addr + O0 * 256 B and addr + (O0 + 2) * 256 B
+  asm volatile("ds_read2st64_b32 %0, %1 offset0:%2 offset1:%3" : "=v"(dst) : "v"(addr), "n"(O0), "n"(O0 + 2));
+}
+__device__ inline void strip_mfma(floatx16& acc, float a, float b) {
+  asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+// fragments of pair Q (pixels 4Q .. 4Q + 3): T < 13 the tap's x fragments, T == 13 the dy fragments
+template <int LGWO, int Q, int T>
+__device__ inline void strip_fetch(floatx2 (&af)[13], floatx2& bf, const unsigned (&aaddr)[13], unsigned baddr) {
+  constexpr int WO = 1 << LGWO, WP = 2 * WO + 3, pix = 4 * Q, oyl = pix >> LGWO, ox = pix & (WO - 1);
+  if constexpr (T < 13) strip_read2<oyl * WP + ox>(af[T], aaddr[T]);
+  else strip_read2<pix>(bf, baddr);
+}
+// The next strip's pieces are ordered asm statements too: a buffer load the compiler knows nothing about (so it cannot drain
+// vmcnt in front of the MFMAs), written to LDS LAG pairs later behind a counted `s_waitcnt vmcnt`.
+typedef float floatx4v __attribute__((ext_vector_type(4)));
+__device__ inline void strip_gload(floatx4v& dst, unsigned off, __amdgpu_buffer_rsrc_t rs) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst) : "v"(off), "s"(rs));
+}
+template <int VM>
+__device__ inline void strip_lwrite(unsigned addr, const floatx4v& v) {
+  asm volatile("s_waitcnt vmcnt(%2)\n\tds_write_b128 %0, %1" : : "v"(addr), "v"(v), "n"(VM) : "memory");
+}
+template <int NL_, int PPP_>
+struct StripPieces {                                            // per-thread state of the next strip's load, all in registers
+  static constexpr int NL = NL_, PPP = PPP_, LAG = 3;
+  floatx4v pf[NL_];
+  unsigned off[NL_];                                            // global byte offsets of the NEXT strip's pieces (0x80000000: reads 0)
+  unsigned dst[NL_];                                            // LDS byte addresses in the OTHER buffer
+  __amdgpu_buffer_rsrc_t rsX, rsY;
+  int nlx;
+};
+// MFMA number I (0 .. 25) of pair Q from slot C; behind it ride, in this order of I: the 14 fragment reads of pair Q + 1
+// (I = 0 .. 13: the last is then 12 MFMAs old at the next pair's wait), the pair's PPP requests of next-strip pieces
+// (I = 14, 16, 18) and the LDS writes of the pieces requested LAG pairs earlier (I = 19, 21, 23).  Nothing but MFMAs and these
+// single instructions sits between two MFMAs: with the loads and writes in FRONT of a pair (first version) the matrix pipe
+// idled ~200 cycles per pair (SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES) = 0.866).
+template <int LGWO, int Q, int I, class PC>
+__device__ inline void strip_steps(floatx16 (&acc)[13], floatx2 (&af)[2][13], floatx2 (&bf)[2], const unsigned (&aaddr)[13], unsigned baddr,
+                                   bool mine, PC& pc) {
+  if constexpr (I < 26) {
+    constexpr int C = Q & 1, H = I / 13, T = I % 13;
+    // slot 12 is the tap both wave halves share (25 taps = 12 + 12 + 1): each half runs it on every other pair, so that both
+    // issue 12.5 taps' worth of MFMAs per pair on average; the two partial tiles are summed in the epilogue
+    if (T < 12 || mine) {                                           // wave-uniform
+      if constexpr (H == 0) strip_mfma(acc[T], af[C][T].x, bf[C].x);
+      else strip_mfma(acc[T], af[C][T].y, bf[C].y);
+    }
+    if constexpr (Q + 1 < 16 && I <= 13) strip_fetch<LGWO, Q + 1, I>(af[C ^ 1], bf[C ^ 1], aaddr, baddr);
+    constexpr int P = PC::PPP, NL = PC::NL, LAG = PC::LAG;
+    if constexpr (I >= 14 && I <= 18 && ((I - 14) & 1) == 0) {
+      constexpr int u = (I - 14) / 2, l = Q * P + u;
+      if constexpr (u < P && l < NL) {
+        if (l < pc.nlx) strip_gload(pc.pf[l], pc.off[l], pc.rsX);   // compile-time after inlining: nlx is a constant of the instantiation
+        else strip_gload(pc.pf[l], pc.off[l], pc.rsY);
+      }
+    }
+    if constexpr (I >= 19 && I <= 23 && ((I - 19) & 1) == 0) {
+      constexpr int u = (I - 19) / 2, lw = (Q - LAG) * P + u;
+      if constexpr (Q >= LAG && u < P && lw < NL) {
+        constexpr int issued = (Q + 1) * P < NL ? (Q + 1) * P : NL;   // pieces requested so far (this pair's included)
+        strip_lwrite<issued - lw - 1>(pc.dst[lw], pc.pf[lw]);
+      }
+    }
+    strip_steps<LGWO, Q, I + 1>(acc, af, bf, aaddr, baddr, mine, pc);
+  }
+}
+template <int LGWO, int T>
+__device__ inline void strip_fetch_first(floatx2 (&af)[2][13], floatx2 (&bf)[2], const unsigned (&aaddr)[13], unsigned baddr) {
+  if constexpr (T <= 13) {
+    strip_fetch<LGWO, 0, T>(af[0], bf[0], aaddr, baddr);
+    strip_fetch_first<LGWO, T + 1>(af, bf, aaddr, baddr);
+  }
+}
+template <int LGWO, int Q, class PC>
+__device__ inline void strip_pairs(floatx16 (&acc)[13], floatx2 (&af)[2][13], floatx2 (&bf)[2], const unsigned (&aaddr)[13], unsigned baddr,
+                                   PC& pc, int th) {
+  if constexpr (Q < 16) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");             // this pair's fragments: issued during the previous pair, 12+ MFMAs old
+    strip_steps<LGWO, Q, 0>(acc, af, bf, aaddr, baddr, (Q & 1) == th, pc);
+    strip_pairs<LGWO, Q + 1>(acc, af, bf, aaddr, baddr, pc, th);
+  }
+}
+
+template <int LGWO>
+__global__ __launch_bounds__(256, 1) void conv_wgrad_strip_kernel(const WgradParams p, int nstrips, int strips_per_img, int strips_per_wg,
+                                                                   int ntile) {
+  using G = StripGeom<LGWO>;
+  constexpr int WO = G::WO, W = G::W, R = G::R, RX = G::RX, WP = G::WP, XROW = G::XROW, XBUF = G::XBUF, BUF = G::BUF;
+  constexpr int NLX = G::NLX, NL = G::NL, NT = 13;
+  constexpr unsigned kOob = 0x80000000u;
+  extern __shared__ __attribute__((aligned(16))) float strip_lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);      // scalar: the tap-half branch is a scalar branch
+  const int th = wave >> 1, nh = wave & 1;
+  // (tile, split): every channel tile of a pixel split on ONE XCD (blocks b and b + 8 share an XCD), so that the tiles that read
+  // the same strips share an L2; needs the split count to be a multiple of 8
+  int tile, z;
+  {
+    const int idx = blockIdx.x;
+    if ((p.ksplit & 7) == 0) {
+      const int j = idx >> 3;
+      tile = j % ntile;
+      z = (idx & 7) + 8 * (j / ntile);
+    } else {
+      tile = idx % ntile;
+      z = idx / ntile;
+    }
+  }
+  const int tile_m = tile / p.tiles_n, tile_n = tile - tile_m * p.tiles_n;
+  const int ci0 = tile_m * 32, co0 = tile_n * 64;
+  const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)p.x_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsY = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.DY), 0, (int)p.dy_bytes, 0x00020000);
+
+  // halo columns x = -1, W, W + 1 of every row of both buffers: zero, never written again
+  for (int i = tid; i < 2 * RX * 3 * 32; i += 256) {
+    const int e = i & 31, rest = i >> 5, c = rest % 3, row = rest / 3;      // row over (buffer, input row)
+    const int bufi = row / RX, rr = row - bufi * RX;
+    strip_lds[bufi * BUF + rr * XROW + (c == 0 ? 0 : (W + c)) * 32 + e] = 0.f;
+  }
+
+  floatx16 acc[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+  // per-thread pieces of a strip load.  x piece l: item = l * 256 + tid over (input row, column, float4 of the 32-channel slice);
+  // a piece past the strip's last one reads out of range (zeros) and lands on a halo cell, which holds zeros anyway
+  constexpr int NP = 16, LAG = 3, PPP = (NL + NP - LAG - 1) / (NP - LAG) > 2 ? (NL + NP - LAG - 1) / (NP - LAG) : 2;   // pieces per pair
+  static_assert(PPP <= 3 && PPP * (NP - LAG) >= NL, "every piece of the next strip must be requested and written within one strip");
+  StripPieces<NL, PPP> pc;
+  pc.rsX = rsX; pc.rsY = rsY; pc.nlx = NLX;
+  int x_rr[NLX], x_dst[NLX];
+  unsigned x_off[NLX];
+#pragma unroll
+  for (int l = 0; l < NLX; ++l) {
+    const int item = l * 256 + tid;
+    const int rr = item / (W * 8), rem = item - rr * (W * 8);
+    const int xc = rem >> 3, q = rem & 7;
+    x_rr[l] = item < G::NX ? rr : 1 << 20;
+    x_dst[l] = item < G::NX ? rr * XROW + (xc + 1) * 32 + q * 4 : (tid & 7) * 4;
+    x_off[l] = (unsigned)(((rr * W + xc) * p.Ci + ci0 + q * 4) * 4);
+  }
+  const int y_dst = XBUF + (tid >> 4) * 64 + (tid & 15) * 4;    // dy piece l: pixel l * 16 + tid / 16, float4 tid % 16 of the 64-channel slice
+  const unsigned y_off = (unsigned)(((tid >> 4) * p.Co + co0 + (tid & 15) * 4) * 4);
+
+  const int s_begin = z * strips_per_wg, s_end = min(nstrips, s_begin + strips_per_wg);
+  // global offsets of strip `sidx`'s pieces (wave-uniform strip coordinates) and their LDS addresses in buffer `buf`
+  auto plan = [&](int sidx, int buf) {
+    const bool live = sidx < s_end;
+    const int b = sidx / strips_per_img, oy0 = (sidx - b * strips_per_img) * R;
+    const unsigned xbase = (unsigned)(((b * p.H + 2 * oy0 - 1) * W) * p.Ci * 4);
+    const unsigned ybase = (unsigned)(((b * p.Ho + oy0) * WO) * p.Co * 4);
+#pragma unroll
+    for (int l = 0; l < NL; ++l) {
+      if (l < NLX) {
+        const int y = 2 * oy0 - 1 + x_rr[l];
+        const bool ok = live && (unsigned)y < (unsigned)p.H;
+        pc.off[l] = ok ? xbase + x_off[l] : kOob;
+        pc.dst[l] = (unsigned)((buf * BUF + x_dst[l]) * 4);
+      } else {
+        pc.off[l] = live ? ybase + (unsigned)((l - NLX) * 16 * p.Co * 4) + y_off : kOob;
+        pc.dst[l] = (unsigned)((buf * BUF + y_dst + (l - NLX) * 16 * 64) * 4);
+      }
+    }
+  };
+
+  // first strip: everything at once
+  plan(s_begin, 0);
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    if (l < NLX) strip_gload(pc.pf[l], pc.off[l], rsX);
+    else strip_gload(pc.pf[l], pc.off[l], rsY);
+  }
+#pragma unroll
+  for (int l = 0; l < NL; ++l) {
+    if (l == 0) strip_lwrite<0>(pc.dst[l], pc.pf[l]);            // vmcnt(0): every piece has arrived
+    else asm volatile("ds_write_b128 %0, %1" : : "v"(pc.dst[l]), "v"(pc.pf[l]) : "memory");
+  }
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // fragment addresses: A = x[ci = lane % 32] of pixel (2j + lane / 32) shifted by the tap; B = dy[co] of the same pixel
+  const int kk = lane >> 5, li = lane & 31;
+  int a_tap[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = t < 12 ? th * 13 + t : 12;                  // slots 0..11: taps 0..11 / 13..24; slot 12: the shared tap 12
+    const int kh = tap / 5, kw = tap - kh * 5;
+    a_tap[t] = (kh * WP + kw) * 32 + kk * 64 + li;
+  }
+  const int b_base = XBUF + kk * 64 + nh * 32 + li;
+  // The k-steps run in PAIRS (pixels 4q .. 4q + 3: the two fragments of a tap lie 2 * 2 * 32 floats apart, one ds_read2st64_b32
+  // fetches both); what rides between the MFMAs of a pair: strip_steps.
+
+  int buf = 0;
+  for (int sidx = s_begin; sidx < s_end; ++sidx, buf ^= 1) {
+    // byte addresses of this buffer's fragments (13 + 1 adds per strip; the pair / tap offsets are immediates)
+    unsigned aaddr[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) aaddr[t] = (unsigned)((buf * BUF + a_tap[t]) * 4);
+    const unsigned baddr = (unsigned)((buf * BUF + b_base) * 4);
+    floatx2 af[2][NT], bf[2];
+    plan(sidx + 1, buf ^ 1);
+    asm volatile("" ::: "memory");
+    strip_fetch_first<LGWO, 0>(af, bf, aaddr, baddr);
+    strip_pairs<LGWO, 0>(acc, af, bf, aaddr, baddr, pc, th);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");           // this wave's LDS writes of the next strip (asm: the compiler does not count them)
+    __syncthreads();
+  }
+
+  // the shared tap: the second half's partial tile goes through LDS (free now) and is added by the first half
+  if (th == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) strip_lds[(nh * 16 + r) * 64 + lane] = acc[12][r];
+  }
+  __syncthreads();
+  if (th == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[12][r] += strip_lds[(nh * 16 + r) * 64 + lane];
+  }
+  // one slab per workgroup: out[z][tap][ci][co]; register r of lane l = D[ci = (r & 3) + 8 (r >> 2) + 4 (l >> 5)][co = l & 31]
+  float* out = p.out + (size_t)z * 25 * p.Ci * p.Co;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int tap = t < 12 ? th * 13 + t : 12;
+    if (t < 12 || th == 0) {
+      float* o = out + (size_t)tap * p.Ci * p.Co + (size_t)ci0 * p.Co + co0 + nh * 32 + li;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[(size_t)((r & 3) + 8 * (r >> 2) + 4 * kk) * p.Co] = acc[t][r];
+    }
+  }
+}
+
 // dw = beta*dw + scale * sum_z slabs[z]; block = 64 float4 columns x 4 slab groups (LDS tree), so few-output layers
 // with many slabs still expose enough parallelism
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int n,
@@ -1235,7 +1500,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_scalar_kernel(const float* _
 struct WgradPlan {
   int mode;     // 0 direct, 1..: mfma config id
   int ksplit, chunk, tiles_m, tiles_n, bkp, taps_in_grid;
+  int always_slab;   // the kernel writes slabs even for one split (beta / scale are applied by the reduce pass)
 };
+
+// 5x5 stride-2 layers the strip-resident kernel takes: Wo = 8 / 16 / 32, whole strips of 64 output pixels
+inline bool strip_ok(int H, int W, int Ci, int Co, int k, int s) {
+  if (k != 5 || s != 2 || (H & 1) || (W & 1) || Ci % 32 || Co % 64) return false;
+  const int Wo = W / 2, Ho = H / 2;
+  if (Wo != 8 && Wo != 16 && Wo != 32) return false;
+  return Ho % (64 / Wo) == 0;
+}
 
 WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
   WgradPlan pl{};
@@ -1255,6 +1529,23 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
     long chunk = std::max(256L, (M + want - 1) / want);
     pl.chunk = (int)chunk;
     pl.ksplit = (int)((M + chunk - 1) / chunk);
+    return pl;
+  }
+  if (strip_ok(H, W, Ci, Co, k, s) && !getenv("BG_WGRAD_NO_STRIP")) {
+    pl.mode = 33;                                             // strip-resident kernel, one slab per workgroup
+    pl.bkp = 2;
+    pl.tiles_m = Ci / 32;
+    pl.tiles_n = Co / 64;
+    const long nstrips = (long)B * (Ho / (64 / Wo));
+    const long ntile = (long)pl.tiles_m * pl.tiles_n;
+    // one workgroup per CU (150 KB of LDS): about 256 workgroups in all, every one with the same number of strips where it divides
+    long ks = std::max(1L, std::min(nstrips, std::max(1L, 256 / ntile)));
+    long spw = (nstrips + ks - 1) / ks;
+    ks = (nstrips + spw - 1) / spw;                           // no workgroup without a strip (its slab would never be written)
+    pl.ksplit = (int)ks;
+    pl.chunk = (int)spw;                                      // strips per workgroup
+    pl.taps_in_grid = 0;
+    pl.always_slab = 1;
     return pl;
   }
   if (Ci == 16 && Co == 32 && k == 5 && s == 2 && !(H & 1) && !(W & 1) && (Wo == 32 || Wo == 64) && !(Ho & 1) && !getenv("BG_NO_C16")) {
@@ -1374,7 +1665,7 @@ extern "C" {
 size_t bg_conv2d_bwd_filter_workspace_bytes(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
   if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize <= 0 || stride <= 0) return 0;
   WgradPlan pl = plan_wgrad(B, H, W, Cin, Cout, ksize, stride);
-  if (pl.ksplit <= 1) return 0;
+  if (pl.ksplit <= 1 && !pl.always_slab) return 0;
   return (size_t)pl.ksplit * ksize * ksize * Cin * Cout * sizeof(float);
 }
 
@@ -1387,7 +1678,8 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
   BG_REQUIRE(bg::aligned16(x) && bg::aligned16(dy) && bg::aligned16(dw), BG_ERR_BAD_ALIGNMENT, "bg_conv2d_bwd_filter: pointers must be 16-byte aligned");
   WgradPlan pl = plan_wgrad(B, H, W, Cin, Cout, ksize, stride);
   const size_t nout = (size_t)ksize * ksize * Cin * Cout;
-  const size_t need = pl.ksplit > 1 ? (size_t)pl.ksplit * nout * sizeof(float) : 0;
+  const bool slabs = pl.ksplit > 1 || pl.always_slab;
+  const size_t need = slabs ? (size_t)pl.ksplit * nout * sizeof(float) : 0;
   BG_REQUIRE(need == 0 || (ws_d && ws_bytes >= need), BG_ERR_WORKSPACE, "bg_conv2d_bwd_filter: workspace %zu bytes < %zu needed", ws_bytes, need);
   WgradParams p;
   memset(&p, 0, sizeof p);
@@ -1440,13 +1732,28 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
       p.order_n = ksize * ksize;
     }
   }
-  p.out = pl.ksplit > 1 ? static_cast<float*>(ws_d) : dw;
+  p.out = slabs ? static_cast<float*>(ws_d) : dw;
   const double flops = 2.0 * p.M * (double)nout;
   int rc;
   if (pl.mode == 0) {
     bg::Launch L(stream, "conv_wgrad_direct", flops, 0);
     bg::launch(wgrad_direct_kernel, dim3(bg::cdiv(nout, 256), pl.ksplit), dim3(256), 0, L.s, p);
     rc = L.done("wgrad_direct_kernel");
+  } else if (pl.mode == 33) {
+    bg::Launch L(stream, "conv_wgrad_mfma", flops, 0);
+    const int lgwo = p.Wo == 32 ? 5 : (p.Wo == 16 ? 4 : 3);
+    const int spi = p.Ho / (64 / p.Wo), nstrips = B * spi, ntile = pl.tiles_m * pl.tiles_n;
+    static std::once_flag strip_attr;
+    std::call_once(strip_attr, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_strip_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripGeom<5>::lds_bytes);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_strip_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripGeom<4>::lds_bytes);
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_strip_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripGeom<3>::lds_bytes);
+    });
+    const dim3 grid((unsigned)(ntile * pl.ksplit));
+    if (lgwo == 5) bg::launch((conv_wgrad_strip_kernel<5>), grid, dim3(256), StripGeom<5>::lds_bytes, L.s, p, nstrips, spi, pl.chunk, ntile);
+    else if (lgwo == 4) bg::launch((conv_wgrad_strip_kernel<4>), grid, dim3(256), StripGeom<4>::lds_bytes, L.s, p, nstrips, spi, pl.chunk, ntile);
+    else bg::launch((conv_wgrad_strip_kernel<3>), grid, dim3(256), StripGeom<3>::lds_bytes, L.s, p, nstrips, spi, pl.chunk, ntile);
+    rc = L.done("conv_wgrad_strip_kernel");
   } else if (pl.mode == 32) {
     bg::Launch L(stream, "conv_wgrad_c16", flops, 0);
     const int spi = p.Ho / 2, nstrips = B * spi;
@@ -1512,7 +1819,7 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     rc = L.done("conv_wgrad_kernel");
   }
   if (rc) return rc;
-  if (pl.ksplit > 1) {
+  if (slabs) {
     bg::Launch L(stream, "conv_wgrad_reduce", 0, (double)(pl.ksplit + 1) * nout * 4);
     if (nout % 4 == 0 && bg::aligned16(ws_d) && pl.ksplit >= 64 && nout <= 65536)
       bg::launch(wgrad_reduce_tall_kernel, dim3(bg::cdiv(nout / 4, 16)), dim3(1024), 0, L.s, static_cast<const float*>(ws_d), dw,

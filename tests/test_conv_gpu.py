@@ -23,6 +23,9 @@ CASES = [
     (128, 4, 4, 64, 64, 1), (128, 8, 8, 32, 64, 2), (128, 8, 8, 64, 32, 2),   # position-major tiles: padding taps skipped (64- and 128-row tiles)
     (1024, 16, 16, 16, 32, 2),                                                 # position-major AND the four phases merged in one workgroup
     (3, 64, 64, 16, 32, 2), (2, 128, 128, 16, 32, 2), (5, 12, 128, 16, 32, 2), (2, 4, 64, 16, 32, 2),   # row-staged 16-channel kernels (C4's outer layers)
+    # strip-resident filter gradient (Ci % 32 == 0, Co % 64 == 0, stride 2, Wo = 8 / 16 / 32): one strip per image, several strips per
+    # image, non-square maps, a strip count the workgroups do not divide, several channel tiles
+    (3, 16, 16, 32, 64, 2), (2, 32, 32, 64, 128, 2), (2, 64, 64, 32, 64, 2), (5, 32, 16, 32, 64, 2), (7, 16, 16, 64, 64, 2), (2, 8, 64, 96, 192, 2),
 ]
 
 
