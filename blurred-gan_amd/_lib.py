@@ -41,6 +41,8 @@ SIGNATURES = {
     "bg_gauss_kernel_1d": (_i, [_f, _f, C.POINTER(_f), _i, C.POINTER(_i)]),
     "bg_blur_workspace_bytes": (_z, [_i, _i, _i, _i, _i]),
     "bg_blur_nhwc_f32": (_i, [_p, _p, _i, _i, _i, _i, _p, _i, _p, _p]),
+    "bg_blur3_lerp_supported": (_i, [_i, _i, _i, _i, _i]),
+    "bg_blur3_lerp_nhwc_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _i, _p, _i, _p]),
     "bg_conv2d_splitk_workspace_bytes": (_z, [_i, _i, _i, _i, _i, _i, _i, _i]),
     "bg_conv2d_fwd": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),
     "bg_conv2d_bwd_data": (_i, [_p, _p, _p, _i, _i, _i, _i, _i, _i, _i, C.POINTER(Epilogue), _p]),

@@ -8,6 +8,7 @@
 //   blur_pass_kernel   generic one-axis pass through L1/L2 with a scratch image in HBM
 //                      (traffic 2x algorithmic); any size / tap count.
 #include "common.h"
+#include <mutex>
 #include <cmath>
 #include <cstdlib>
 #include <type_traits>
@@ -221,9 +222,14 @@ inline RowsGeom rows_geom(int H, int W, int C, int T) {
   return g;
 }
 
+// Three-source form (x2 != nullptr; the critic's batch of wgan.py:138-139,239-240 in ONE launch): images
+// [0, Bs) are blurred from x, [Bs, 2 Bs) from x2 and [2 Bs, 3 Bs) from x-hat = x2 + alpha[b] * (x - x2), formed while the rows are
+// copied into LDS (the expression of lerp_kernel, so the result is bit-identical to lerp followed by blur) -- x-hat never exists
+// in memory, and 3 Bs x nb workgroups pipeline through the CUs where three launches of Bs x nb each ran one after the other.
 __global__ __launch_bounds__(kRowsThreads) void blur_rows_kernel(const float* __restrict__ x, float* __restrict__ y, int H, int W, int C,
                                                                  int nb, int Qp, int Wp, int xfloats, const float* __restrict__ taps, int T,
-                                                                 FastDiv dQ4) {
+                                                                 FastDiv dQ4, const float* __restrict__ x2, const float* __restrict__ alpha,
+                                                                 int Bs) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NTH = kRowsThreads, NW = NTH / 64;
   const int Q = W * C, q4 = Q >> 2, half = T >> 1;
@@ -235,7 +241,8 @@ __global__ __launch_bounds__(kRowsThreads) void blur_rows_kernel(const float* __
   const int img = blockIdx.x / nb, rb = blockIdx.x - img * nb, r0 = rb * kRowsBlock;
   const int ks = max(0, r0 - half), ke = min(H, r0 + kRowsBlock + half);       // source rows [ks, ke)
   const int nk = ke - ks, nk2 = (nk + 1) & ~1;
-  const float* xi = x + (size_t)img * H * Q;
+  const int grp = x2 ? img / Bs : 0, bimg = x2 ? img - grp * Bs : img;          // source group and image within it
+  const float* xi = (grp == 1 ? x2 : x) + (size_t)bimg * H * Q;
   float* yi = y + (size_t)img * H * Q;
   for (int j = tid; j < T + 2 * kTzPad; j += NTH) tz[j] = (j >= kTzPad && j < kTzPad + T) ? taps[j - kTzPad] : 0.f;
   // what the copy below does not write must read as zero: the columns past the row (when W*C is not a multiple of 32) and the
@@ -246,7 +253,19 @@ __global__ __launch_bounds__(kRowsThreads) void blur_rows_kernel(const float* __
   }
   if (nk2 != nk)
     for (int e = tid; e < Qp; e += NTH) X[nk * Qp + e] = 0.f;
-  {
+  if (grp == 2) {                                              // x-hat rows: r + a * (f - r), r = x2, f = x (workgroup-uniform branch)
+    const float4* sf = reinterpret_cast<const float4*>(xi + (size_t)ks * Q);
+    const float4* sr = reinterpret_cast<const float4*>(x2 + (size_t)bimg * H * Q + (size_t)ks * Q);
+    const float a = alpha[bimg];
+    const int total4 = nk * q4;
+    for (int i = tid; i < total4; i += NTH) {
+      const int row = fdiv(i, dQ4), c4 = i - row * q4;
+      const float4 f = sf[i], r = sr[i];
+      float4 v;
+      v.x = r.x + a * (f.x - r.x); v.y = r.y + a * (f.y - r.y); v.z = r.z + a * (f.z - r.z); v.w = r.w + a * (f.w - r.w);
+      *reinterpret_cast<float4*>(X + row * Qp + 4 * c4) = v;
+    }
+  } else {
     const float4* src = reinterpret_cast<const float4*>(xi + (size_t)ks * Q);
     const int total4 = nk * q4;
     for (int i = tid; i < total4; i += NTH) {
@@ -1243,12 +1262,7 @@ int launch_strip(dim3 grid, hipStream_t s, const float* x, float* y, int B, int 
 #endif
   auto kern = blur_strip_kernel<C, P>;
   size_t lds = StripCfg<C, P>::lds_bytes;
-  static bool attr = false;                                   // one flag per instantiation
-  if (!attr && lds > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "blur_strip: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr = true;
-  }
+  if (lds > 64 * 1024) BG_LDS_ATTR_ONCE(kern, lds, "blur_strip");      // one flag per instantiation
   bg::launch(kern, grid, dim3(256), lds, s, x, y, B, H, W, strips, taps, T STRIP_DBG_ARG);
   return BG_OK;
 }
@@ -1358,27 +1372,17 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   };
   if (path == 5) {
     const RowsGeom g = rows_geom(H, W, C, n_taps);
-    static bool attr_r = false;
-    if (!attr_r) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_rows_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
-      if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "bg_blur_nhwc_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      attr_r = true;
-    }
+    BG_LDS_ATTR_ONCE(blur_rows_kernel, 80 * 1024, "bg_blur_nhwc_f32");
     bg::Launch L(stream, "blur_rows", flops, bytes);
     bg::launch(blur_rows_kernel, dim3((unsigned)(B * g.nb)), dim3(kRowsThreads), g.lds, s, x, y, H, W, C, g.nb, g.Qp, g.Wp, g.xfloats,
-                       taps_d, n_taps, magic((unsigned)(g.Q / 4)));
+                       taps_d, n_taps, magic((unsigned)(g.Q / 4)), nullptr, nullptr, B);
     return L.done("blur_rows_kernel");
   }
   {
     const int Hp = (H + 31) / 32 * 32, Wp = (W + 31) / 32 * 32;
     const size_t lds_m = ((size_t)2 * C * Hp * (Wp + 1) + n_taps + 2 * kTzPad) * sizeof(float);
     if (path == 0) {
-      static bool attr_m = false;
-      if (!attr_m) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsCap);
-        if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "bg_blur_nhwc_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-        attr_m = true;
-      }
+      BG_LDS_ATTR_ONCE(blur_mfma_kernel, kFusedLdsCap, "bg_blur_nhwc_f32");
       bg::Launch L(stream, "blur_mfma", flops, bytes);
       bg::launch(blur_mfma_kernel, dim3(B), dim3(kMfmaBlurThreads), lds_m, s, x, y, H, W, C, Hp, Wp, taps_d, n_taps, magic((unsigned)C),
                          magic((unsigned)W));
@@ -1402,13 +1406,7 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   }
   const size_t lds = fused_lds_bytes(H, W, C);
   if (path == 1) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(blur_fused_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)kFusedLdsCap);
-      if (e != hipSuccess) return bg::fail(BG_ERR_HIP, "bg_blur_nhwc_f32: hipFuncSetAttribute: %s", hipGetErrorString(e));
-      attr_set = true;
-    }
+    BG_LDS_ATTR_ONCE(blur_fused_kernel, kFusedLdsCap, "bg_blur_nhwc_f32");
     bg::Launch L(stream, "blur_fused", flops, bytes);
     bg::launch(blur_fused_kernel, dim3(B), dim3(kFusedThreads), lds, s, x, y, H, W, C, taps_d, n_taps);
     return L.done("blur_fused_kernel");
@@ -1443,12 +1441,8 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   int rows_per = (int)std::min<size_t>(8, std::max<size_t>(1, (48 * 1024 / sizeof(float)) / (size_t)WC));
   const size_t lds_w = ((size_t)rows_per * WC + n_taps + kR + 4) * sizeof(float);
   if (lds_h <= 140 * 1024 && lds_w <= 140 * 1024) {
-    static bool attr_set2 = false;
-    if (!attr_set2) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur_lines_h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(blur_lines_w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 140 * 1024);
-      attr_set2 = true;
-    }
+    BG_LDS_ATTR_ONCE(blur_lines_h_kernel, 140 * 1024, "bg_blur_nhwc_f32");
+    BG_LDS_ATTR_ONCE(blur_lines_w_kernel, 140 * 1024, "bg_blur_nhwc_f32");
     const int strips = (int)bg::cdiv(WC, kStripW);
     {
       bg::Launch L(stream, "blur_lines_h", flops / 2, bytes);
@@ -1472,6 +1466,37 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
   bg::Launch L(stream, "blur_pass_w", flops / 2, bytes);
   bg::launch(blur_pass_kernel<1>, dim3(grid), dim3(kBlurThreads), 0, s, tmp_d, y, total, H, W, C, taps_d, n_taps);
   return L.done("blur_pass_kernel<W>");
+}
+
+int bg_blur3_lerp_supported(int B, int H, int W, int C, int n_taps) {
+  if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || n_taps < 1 || !(n_taps & 1)) return 0;
+  return blur_path(3 * B, H, W, C, n_taps) == 5 ? 1 : 0;
+}
+
+int bg_blur3_lerp_nhwc_f32(const float* f, const float* r, const float* alpha_b, float* y3, int B, int H, int W, int C, const float* taps_d,
+                           int n_taps, void* stream) {
+  BG_REQUIRE(f && r && alpha_b && y3 && taps_d, BG_ERR_NULL, "bg_blur3_lerp_nhwc_f32: null pointer");
+  BG_REQUIRE(B > 0 && H > 0 && W > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_blur3_lerp_nhwc_f32: B=%d H=%d W=%d C=%d", B, H, W, C);
+  BG_REQUIRE(n_taps >= 1 && (n_taps & 1), BG_ERR_BAD_SHAPE, "bg_blur3_lerp_nhwc_f32: tap count %d must be odd", n_taps);
+  BG_REQUIRE(bg::aligned16(f) && bg::aligned16(r) && bg::aligned16(y3), BG_ERR_BAD_ALIGNMENT, "bg_blur3_lerp_nhwc_f32: f / r / y3 must be 16-byte aligned");
+  BG_REQUIRE(bg_blur3_lerp_supported(B, H, W, C, n_taps), BG_ERR_UNSUPPORTED,
+             "bg_blur3_lerp_nhwc_f32: %dx%dx%d at %d taps is not on the row-block kernel (see bg_blur3_lerp_supported): run bg_lerp_f32 and three bg_blur_nhwc_f32",
+             H, W, C, n_taps);
+  const RowsGeom g = rows_geom(H, W, C, n_taps);
+  BG_LDS_ATTR_ONCE(blur_rows_kernel, 80 * 1024, "bg_blur3_lerp_nhwc_f32");
+  const size_t total = (size_t)3 * B * H * W * C;
+  bg::Launch L(stream, "blur_rows3", 4.0 * n_taps * (double)total, (8.0 / 3.0 + 4.0) * (double)total);     // reads f and r (x-hat rides on them), writes three
+  FastDiv dq;
+  {
+    const unsigned d = (unsigned)(g.Q / 4);
+    unsigned sft = 0;
+    while ((1u << sft) < d) ++sft;
+    dq.sh = 20 + sft;
+    dq.mul = (unsigned)(((1ull << dq.sh) + d - 1) / d);
+  }
+  bg::launch(blur_rows_kernel, dim3((unsigned)(3 * B * g.nb)), dim3(kRowsThreads), g.lds, static_cast<hipStream_t>(stream), f, y3, H, W, C, g.nb,
+             g.Qp, g.Wp, g.xfloats, taps_d, n_taps, dq, r, alpha_b, B);
+  return L.done("blur_rows_kernel(3 sources)");
 }
 
 }  // extern "C"

@@ -5,6 +5,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include "../../include/bgan.h"
 #include "launch.h"
 
@@ -55,6 +56,22 @@ struct Launch {
     return BG_OK;
   }
 };
+
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per call site, safe under concurrent host threads (the header promises
+// thread safety for distinct streams): the flag and the result live beside the call.  BG_LDS_ATTR_ONCE returns the error;
+// BG_LDS_ATTR_ONCE_V ignores it (the launch that follows reports it).
+#define BG_LDS_ATTR_ONCE(kern, bytes, what)                                                                                      \
+  do {                                                                                                                           \
+    static std::once_flag flag_;                                                                                                 \
+    static hipError_t err_ = hipSuccess;                                                                                         \
+    std::call_once(flag_, [&] { err_ = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); }); \
+    if (err_ != hipSuccess) return bg::fail(BG_ERR_HIP, what ": hipFuncSetAttribute: %s", hipGetErrorString(err_));              \
+  } while (0)
+#define BG_LDS_ATTR_ONCE_V(kern, bytes)                                                                                          \
+  do {                                                                                                                           \
+    static std::once_flag flag_;                                                                                                 \
+    std::call_once(flag_, [&] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)); }); \
+  } while (0)
 
 #define BG_REQUIRE(cond, code, ...) \
   do {                              \

@@ -393,12 +393,10 @@ int try_conv_c16(int bwd_data, const float* a, const float* w, float* c, int B, 
     const double flops = 2.0 * B * (double)Hs * Ws * Cin * Cout * 25;
     Launch L(stream, "conv_c16_dgrad", flops, 0);
     if (Ws == 64) {
-      static bool attr = false;
-      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_dgrad_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+      BG_LDS_ATTR_ONCE_V(conv_c16_dgrad_kernel<64>, 150 * 1024);
       bg::launch((conv_c16_dgrad_kernel<64>), grid, dim3(256), lds, L.s, p);
     } else {
-      static bool attr = false;
-      if (!attr) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_dgrad_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024); attr = true; }
+      BG_LDS_ATTR_ONCE_V(conv_c16_dgrad_kernel<32>, 150 * 1024);
       bg::launch((conv_c16_dgrad_kernel<32>), grid, dim3(256), lds, L.s, p);
     }
     *taken = 1;
@@ -420,12 +418,8 @@ int try_conv_c16(int bwd_data, const float* a, const float* w, float* c, int B, 
     const dim3 grid((unsigned)std::min(p.nstrips, 256));
     const double flops = 2.0 * B * (double)Ho * Wo * Cin * Cout * 25;
     Launch L(stream, "conv_c16_fwd", flops, 0);
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_fwd_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_c16_fwd_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr = true;
-    }
+    BG_LDS_ATTR_ONCE_V(conv_c16_fwd_kernel<64>, 150 * 1024);
+    BG_LDS_ATTR_ONCE_V(conv_c16_fwd_kernel<32>, 150 * 1024);
     if (Wo == 64) bg::launch((conv_c16_fwd_kernel<64>), grid, dim3(256), lds, L.s, p);
     else bg::launch((conv_c16_fwd_kernel<32>), grid, dim3(256), lds, L.s, p);
     *taken = 1;

@@ -1096,11 +1096,7 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     static const int no_tn = getenv("BG_NO_THIN_N_MFMA") ? 1 : 0;
     if (rect && pl + kTnCols + (k - 1 - pl) <= kTnPx && !no_tn) {
       const size_t lds = ((size_t)(kTnRows + k - 1) * kTnPx * kTnCS + (size_t)k * kTnCc * 16 + 4 * kTnPx * 17) * sizeof(float);
-      static bool attr_tn = false;
-      if (!attr_tn) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_n_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024);
-        attr_tn = true;
-      }
+      BG_LDS_ATTR_ONCE_V(conv_thin_n_mfma_kernel, 100 * 1024);
       snprintf(name, sizeof name, "conv_thin_n_mfma_%s", tag);
       bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
       bg::launch(conv_thin_n_mfma_kernel, dim3(bg::cdiv(p.Wd, kTnCols), bg::cdiv(p.Hd, kTnRows), p.B), dim3(256), lds, L.s, p, k, pt, pl);
@@ -1125,13 +1121,9 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
       tiles_y = std::max(tiles_y, (int)bg::cdiv(p.ph[i].Ha, kThinTH));
     }
     if (lds <= 150 * 1024 && (size_t)p.B * p.nphase <= 65535) {
-      static bool attr_set = false;
-      if (!attr_set) {
-#define BG_TNP_ATTR(CKv, TWv) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_thin_n_patch_kernel<CKv, TWv>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)
-        BG_TNP_ATTR(16, 32); BG_TNP_ATTR(32, 32); BG_TNP_ATTR(64, 32); BG_TNP_ATTR(16, 16); BG_TNP_ATTR(32, 16); BG_TNP_ATTR(64, 16);
+#define BG_TNP_ATTR(CKv, TWv) BG_LDS_ATTR_ONCE_V((conv_thin_n_patch_kernel<CKv, TWv>), 150 * 1024)
+      BG_TNP_ATTR(16, 32); BG_TNP_ATTR(32, 32); BG_TNP_ATTR(64, 32); BG_TNP_ATTR(16, 16); BG_TNP_ATTR(32, 16); BG_TNP_ATTR(64, 16);
 #undef BG_TNP_ATTR
-        attr_set = true;
-      }
       snprintf(name, sizeof name, "conv_thin_n_patch_%s", tag);
       dim3 grid(tiles_x, tiles_y, p.B * p.nphase);
       bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));

@@ -1743,12 +1743,9 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     bg::Launch L(stream, "conv_wgrad_mfma", flops, 0);
     const int lgwo = p.Wo == 32 ? 5 : (p.Wo == 16 ? 4 : 3);
     const int spi = p.Ho / (64 / p.Wo), nstrips = B * spi, ntile = pl.tiles_m * pl.tiles_n;
-    static std::once_flag strip_attr;
-    std::call_once(strip_attr, [] {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_strip_kernel<5>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripGeom<5>::lds_bytes);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_strip_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripGeom<4>::lds_bytes);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_strip_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)StripGeom<3>::lds_bytes);
-    });
+    BG_LDS_ATTR_ONCE_V(conv_wgrad_strip_kernel<5>, StripGeom<5>::lds_bytes);
+    BG_LDS_ATTR_ONCE_V(conv_wgrad_strip_kernel<4>, StripGeom<4>::lds_bytes);
+    BG_LDS_ATTR_ONCE_V(conv_wgrad_strip_kernel<3>, StripGeom<3>::lds_bytes);
     const dim3 grid((unsigned)(ntile * pl.ksplit));
     if (lgwo == 5) bg::launch((conv_wgrad_strip_kernel<5>), grid, dim3(256), StripGeom<5>::lds_bytes, L.s, p, nstrips, spi, pl.chunk, ntile);
     else if (lgwo == 4) bg::launch((conv_wgrad_strip_kernel<4>), grid, dim3(256), StripGeom<4>::lds_bytes, L.s, p, nstrips, spi, pl.chunk, ntile);
@@ -1758,12 +1755,8 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     bg::Launch L(stream, "conv_wgrad_c16", flops, 0);
     const int spi = p.Ho / 2, nstrips = B * spi;
     const size_t lds = std::max((size_t)2 * kC16Rows * 2 * (p.Wo + 2) * 16, (size_t)25 * 2 * 4 * 64) * sizeof(float);
-    static bool attr = false;
-    if (!attr) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_c16_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_c16_kernel<32>), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-      attr = true;
-    }
+    BG_LDS_ATTR_ONCE_V(conv_wgrad_c16_kernel<64>, 150 * 1024);
+    BG_LDS_ATTR_ONCE_V(conv_wgrad_c16_kernel<32>, 150 * 1024);
     if (p.Wo == 64) bg::launch((conv_wgrad_c16_kernel<64>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nstrips, spi);
     else bg::launch((conv_wgrad_c16_kernel<32>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nstrips, spi);
     rc = L.done("conv_wgrad_c16_kernel");

@@ -255,16 +255,35 @@ class Net:
             return ops.blur_nhwc(x, y, taps, nt, tmp)
 
     # ------------------------------------------------------------------ forward
-    def forward(self, ctx: Context, inputs, training=False, masks=None, seed=0):
+    def forward(self, ctx: Context, inputs, training=False, masks=None, seed=0, lerp_alpha=None, lerp_out=None):
         """inputs: a tensor [B,...] or a list of tensors concatenated along the batch.  ``training`` switches
-        Dropout and BatchNormalization exactly as Keras' ``training=`` argument does."""
+        Dropout and BatchNormalization exactly as Keras' ``training=`` argument does.
+        ``lerp_alpha`` (with inputs = [f, r]): a third batch slice x-hat = r + alpha (f - r) follows the two (wgan.py:239).  Behind
+        a blur layer of a geometry the row-block kernel takes, all three slices are blurred by ONE launch that forms x-hat on the
+        fly (bg_blur3_lerp_nhwc_f32); otherwise x-hat is written to ``lerp_out`` by bg_lerp_f32 and joins the list."""
         if self.store.tr_dirty:
             self.prepare_weights()
         if not isinstance(inputs, (list, tuple)):
             inputs = [inputs]
         B = ctx.B
-        assert sum(int(t.shape[0]) for t in inputs) == B, "batch mismatch"
-        if self.blur is not None:
+        fused3 = False
+        if lerp_alpha is not None:
+            f, r = inputs
+            n = int(f.shape[0])
+            assert 3 * n == B
+            if self.blur is not None:
+                H, W, C = self.in_shape
+                taps, nt = self.blur_taps(H, W)
+                fused3 = not os.environ.get("BGAN_NO_FUSED_BLUR3") and ops.blur3_lerp_supported(n, H, W, C, nt)
+            if fused3:
+                with ops.trace_range("blur"):
+                    ops.blur3_lerp(f.view(n, *self.in_shape), r.view(n, *self.in_shape), lerp_alpha, ctx.a0, taps, nt)
+            else:
+                inputs = [f, r, ops.lerp(r, f, lerp_alpha, lerp_out)]
+        assert fused3 or sum(int(t.shape[0]) for t in inputs) == B, "batch mismatch"
+        if fused3:
+            x = ctx.a0
+        elif self.blur is not None:
             o = 0
             for t in inputs:
                 n = int(t.shape[0])

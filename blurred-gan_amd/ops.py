@@ -114,6 +114,20 @@ def blur_nhwc(x, y, taps_d, n_taps, tmp=None):
     return y
 
 
+def blur3_lerp_supported(B, H, W, Cc, n_taps):
+    return bool(_lib.load().bg_blur3_lerp_supported(B, H, W, Cc, n_taps))
+
+
+def blur3_lerp(f, r, alpha_b, y3, taps_d, n_taps):
+    """y3 = [blur(f); blur(r); blur(r + alpha (f - r))] in one launch (include/bgan.h bg_blur3_lerp_nhwc_f32)."""
+    _f32(f, r, alpha_b, y3, taps_d)
+    B, H, W, Cc = f.shape
+    assert r.shape == f.shape and tuple(y3.shape) == (3 * B, H, W, Cc) and alpha_b.numel() == B
+    check(_lib.load().bg_blur3_lerp_nhwc_f32(_ptr(f), _ptr(r), _ptr(alpha_b), _ptr(y3), B, H, W, Cc, _ptr(taps_d), n_taps, _stream()),
+          "bg_blur3_lerp_nhwc_f32")
+    return y3
+
+
 # ------------------------------------------------------------------ conv family
 def conv2d_fwd(x, wT, y, ksize, stride, epi=None):
     """x [B,H,W,Cin], wT [k*k,Cout,Cin] -> y [B,Ho,Wo,Cout]."""

@@ -361,9 +361,11 @@ class WGAN:
             # the image gradient is taken for rows [2B, 3B) only.
             a = self._inj("alpha")
             a = self._as_device(a).view(B) if a is not None else self._uniform("alpha", (B,))
-            xhat = ops.lerp(reals, fakes, a, self._buf("xhat", tuple(reals.shape)))
             c3 = D.context(3 * B, "fr3", drop_rows=2 * B)
-            s3 = D.forward(c3, [fakes, reals, xhat], training=True, masks=masks, seed=seed).view(3 * B)
+            # x-hat = reals + a (fakes - reals) (wgan.py:239) joins the batch inside forward: behind the blur it is formed on the fly
+            # by the one launch that blurs all three slices (bg_blur3_lerp_nhwc_f32), else bg_lerp_f32 writes it to the buffer
+            s3 = D.forward(c3, [fakes, reals], training=True, masks=masks, seed=seed, lerp_alpha=a,
+                           lerp_out=self._buf("xhat", tuple(reals.shape))).view(3 * B)
             fs, rs = s3[:B], s3[B:2 * B]
             ds3 = self._buf("ds3", (3 * B,))
             ops.fill(ds3[2 * B:], 1.0)

@@ -74,6 +74,15 @@ size_t bg_blur_workspace_bytes(int B, int H, int W, int C, int n_taps);
 int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C,
                      const float* taps_d, int n_taps, float* tmp_d, void* stream);
 
+/* The critic's batch of one discriminator_step in ONE launch (wgan.py:138-139 fakes and reals, wgan.py:239-240 x-hat):
+ *   y3[0:B] = blur(f), y3[B:2B] = blur(r), y3[2B:3B] = blur(r + alpha[b] * (f - r))
+ * x-hat is formed while its rows are staged (the expression of bg_lerp_f32: bit-identical to bg_lerp_f32 followed by bg_blur_nhwc_f32)
+ * and never written to memory.  Only geometries of the row-block kernel (images up to 64 x 64, <= 4 channels, >= 13 taps;
+ * bg_blur3_lerp_supported tells) -- anything else returns BG_ERR_UNSUPPORTED and the caller runs the three separate calls. */
+int bg_blur3_lerp_supported(int B, int H, int W, int C, int n_taps);
+int bg_blur3_lerp_nhwc_f32(const float* f, const float* r, const float* alpha_b, float* y3, int B, int H, int W, int C,
+                           const float* taps_d, int n_taps, void* stream);
+
 /* ---- convolution family: layers.Conv2D / Conv2DTranspose (demo_celeba.py:62-119,
  *      demo_mnist.py:60-81) and their tape gradients (wgan.py:140,166,244) -------------------
  * Geometry is TF 'SAME' for a kxk kernel (k odd, k*k <= 25), stride 1 or 2:

@@ -161,3 +161,51 @@ def test_blur_rejects_bad_arguments():
     taps = torch.ones(4, device="cuda")
     with pytest.raises(ValueError):
         ops.blur_nhwc(x, torch.empty_like(x), taps, 4)          # even tap count
+
+
+@pytest.mark.parametrize("B,H,W,C,sigma", [(5, 64, 64, 3, 5.0), (3, 32, 32, 3, 3.0), (4, 28, 28, 4, 2.5), (2, 64, 48, 1, 4.0), (7, 40, 64, 3, 10.5)])
+def test_three_source_blur_with_the_lerp_formed_on_the_fly(B, H, W, C, sigma):
+    """bg_blur3_lerp_nhwc_f32 (wgan.py:138-139, 239-240 in one launch): [blur(f); blur(r); blur(r + a (f - r))] must be BIT-identical
+    to bg_lerp_f32 followed by three bg_blur_nhwc_f32 calls -- x-hat is formed with the same expression while its rows are staged."""
+    from blurred_gan_amd import ops
+    g = torch.Generator(device="cuda").manual_seed(B * 100 + H)
+    f = torch.rand(B, H, W, C, device="cuda", generator=g) * 2 - 1
+    r = torch.rand(B, H, W, C, device="cuda", generator=g) * 2 - 1
+    a = torch.rand(B, device="cuda", generator=g)
+    ks, se, nt = ops.blur_policy(sigma, H, W)
+    taps = torch.tensor(ops.gauss_kernel_1d(se, ks), device="cuda")
+    assert ops.blur3_lerp_supported(B, H, W, C, nt), (H, W, C, nt)
+    y3 = ops.blur3_lerp(f, r, a, torch.empty(3 * B, H, W, C, device="cuda"), taps, nt)
+    xhat = ops.lerp(r, f, a, torch.empty_like(f))
+    nb = ops.blur_workspace_bytes(B, H, W, C, nt)
+    tmp = torch.empty(nb // 4 + 4, device="cuda") if nb else None
+    for i, src in enumerate((f, r, xhat)):
+        want = ops.blur_nhwc(src, torch.empty_like(f), taps, nt, tmp)
+        assert torch.equal(y3[i * B:(i + 1) * B], want), i
+    # geometries of other kernels are refused, not silently run elsewhere
+    assert not ops.blur3_lerp_supported(2, 28, 28, 1, 3) and not ops.blur3_lerp_supported(2, 128, 128, 3, 31)
+    with pytest.raises(ValueError):
+        ops.blur3_lerp(f[:, :, :, :1].contiguous().expand(B, H, W, 1).contiguous()[:, :8, :8], r[:, :8, :8, :1].contiguous(), a,
+                       torch.empty(3 * B, 8, 8, 1, device="cuda"), taps, 3)
+
+
+def test_fused_critic_batch_equals_separate_launches(tmp_path, monkeypatch):
+    """The whole discriminator_step with the three-source launch against BGAN_NO_FUSED_BLUR3=1 (lerp + three blurs): bit-identical
+    state after two steps."""
+    import blurred_gan_amd as bg
+    from blurred_gan_amd import models
+
+    def run(no_fuse):
+        if no_fuse:
+            monkeypatch.setenv("BGAN_NO_FUSED_BLUR3", "1")
+        else:
+            monkeypatch.delenv("BGAN_NO_FUSED_BLUR3", raising=False)
+        bg.set_seed(77)
+        gen, disc = models.DCGANGenerator(arch="celeba64"), models.DCGANDiscriminator(arch="celeba64")
+        hp = bg.BlurredWGANGP.HyperParameters(initial_blur_std=5.0, global_batch_size=8, batch_size=8)
+        gan = bg.BlurredWGANGP(gen, disc, hp, bg.TrainingConfig(log_dir=str(tmp_path / "log")), step_replay=False)
+        g = torch.Generator().manual_seed(1)
+        out = [gan.train_on_batch((torch.rand(8, 64, 64, 3, generator=g) * 2 - 1).cuda()) for _ in range(2)]
+        return out, gan.discriminator.store.theta.clone(), gan.generator.store.theta.clone()
+    a, b = run(False), run(True)
+    assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
