@@ -13,7 +13,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libbgan_hip.so")
-SOURCES = ["runtime.hip", "blur.hip", "conv_igemm.hip", "conv_rows.hip", "conv_c16.hip", "conv_wgrad.hip", "misc.hip", "comm.hip", "program.hip"]
+SOURCES = ["runtime.hip", "blur.hip", "blur_panel.hip", "conv_igemm.hip", "conv_rows.hip", "conv_c16.hip", "conv_wgrad.hip", "misc.hip", "comm.hip", "program.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-ffp-contract=off"]   # fp contraction off: fmaf() is explicit where wanted

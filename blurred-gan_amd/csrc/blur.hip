@@ -8,6 +8,7 @@
 //   blur_pass_kernel   generic one-axis pass through L1/L2 with a scratch image in HBM
 //                      (traffic 2x algorithmic); any size / tap count.
 #include "common.h"
+#include "blur_panel.h"
 #include <mutex>
 #include <cmath>
 #include <cstdlib>
@@ -1321,6 +1322,7 @@ int bg_gauss_kernel_1d(float sigma_eff, float kernel_size, float* taps_host, int
 //   2 two transposing banded-Toeplitz passes (C <= 4)                           -- scratch
 //   3 line kernels / generic passes                                             -- scratch
 //   4 fused streaming strips, both passes in one launch (1 or 3 channels, <= 65 taps, larger than 64x64) -- no scratch
+//   6 32-row panels, both band passes in one launch (RGB, > 65 taps, up to 256 pixels wide)            -- no scratch
 static int blur_path(int B, int H, int W, int C, int n_taps) {
   static const int strip_min = getenv("BG_BLUR_STRIP_MIN_SIZE") ? atoi(getenv("BG_BLUR_STRIP_MIN_SIZE")) : 65;
   static const int strip_max_taps = getenv("BG_BLUR_STRIP_MAX_TAPS") ? atoi(getenv("BG_BLUR_STRIP_MAX_TAPS")) : 65;
@@ -1338,6 +1340,9 @@ static int blur_path(int B, int H, int W, int C, int n_taps) {
   if (H <= 64 && W <= 64 && C <= 16 && n_taps >= mfma_min_taps && lds_m <= kFusedLdsCap) return 0;
   const bool fused_fits = fused_lds_bytes(H, W, C) <= kFusedLdsCap && n_taps <= 500;
   const bool band_ok = C <= 4 && (size_t)B * H * W * C < (1ull << 31);
+  // both band passes in one launch (32-row panels, pass-1 result in LDS): RGB images of 96 ... 256 pixels a side beyond 65 taps
+  static const int panel_min = getenv("BG_BLUR_PANEL_MIN_TAPS") ? atoi(getenv("BG_BLUR_PANEL_MIN_TAPS")) : 67;
+  if (band_ok && n_taps >= panel_min && (H > 64 || W > 64) && bg::blur_panel_ok(B, H, W, C, n_taps) && !getenv("BG_BLUR_NO_PANEL")) return 6;
   // measured (tools/blur_sweep.py): the band kernels beat the line kernels at every tap count (128x128x3: 38-43 us against
   // 43-68; 256x256x3: 60-72 against 97-170)
   // ... and the sliding-window fused kernel from about 31 taps up (128x128x1: 28 us both at 31 taps, 37 against 77 at 129)
@@ -1370,6 +1375,13 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
     f.mul = (unsigned)(((1ull << f.sh) + d - 1) / d);
     return f;
   };
+  if (path == 6) {
+    bg::Launch L(stream, "blur_panel", flops, bytes);
+    const int rc = bg::blur_panel_launch(x, y, B, H, W, taps_d, n_taps, s);
+    if (rc) return rc;
+    L.exec_flops(bg::blur_panel_exec_flops(B, H, W, n_taps));
+    return L.done("blur_panel_kernel");
+  }
   if (path == 5) {
     const RowsGeom g = rows_geom(H, W, C, n_taps);
     BG_LDS_ATTR_ONCE(blur_rows_kernel, 80 * 1024, "bg_blur_nhwc_f32");

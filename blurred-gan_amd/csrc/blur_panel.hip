@@ -1,0 +1,261 @@
+// Wide-tap Gaussian blur, BOTH passes in one launch (gaussian_blur.py:116-130 at the callback's default sigma 23.5 -> 143 taps and at
+// maximum_reasonable_std(256) -> 255 taps, callbacks.py:49,74; BASELINE.json configs[4]).
+//
+// blur_band_t_kernel x 2 (blur.hip) runs one banded Toeplitz product per launch through a scratch image and stores every result
+// TRANSPOSED; its notes price the transposed stores at 19 of 101 us and the two launches' memory instructions as almost additive
+// to the MFMA time.  Here a workgroup owns a PANEL of 32 output rows of one image and nothing leaves the CU between the passes:
+//   pass 1 (H):  Y[32][W*3] = T_H[32 x K] * X[K][W*3],  K = the rows within half a kernel of the panel.  Wave w owns pixels
+//                [32w, 32w + 32) x RGB = three 32-column MFMA tiles whose columns are the STRIDED sets {3l + c}: one
+//                buffer_load_dwordx3 per lane and k-pair (lanes 0..31 row k, 32..63 row k + 1) IS the B operand of the three
+//                MFMAs -- no LDS staging of X, no barrier, nothing shared between waves; eight loads in flight per wave.
+//                The Toeplitz fragment comes from a zero-padded tap table in LDS (one ds_read per k-pair, shared by the 3 MFMAs).
+//   Y stays in LDS (32 x (W*3 + 1) floats, 98 KB at W = 256; odd pitch: pass 2 reads it with lanes along rows).
+//   pass 2 (W):  Z^T[x][r] = sum_x' T_W[x][x'] * Y[r][x', c] per channel, computed TRANSPOSED (A = Toeplitz, B = Y^T from LDS): a
+//                lane ends with 4 consecutive pixels x 3 channels of ONE output row = 12 contiguous floats -> three float4 stores,
+//                straight into the NHWC result (no transposed store, no scratch image).  Wave w owns the pixel tile [32w, 32w+32).
+// Both passes contract over the band only (rows / columns outside the image: the range is clipped; partial pairs: zero taps).
+// Workgroups are dealt so that the two a CU runs (512 for 64 images of 256 rows on 256 CUs) are one long-band and one short-band
+// panel (middle panels contract over 32 + T - 1 rows, border panels over fewer).
+// MFMA-bound: 2 * 3 * (K_H + K_W) / 2 MFMAs of 32x32x2 per wave; HBM traffic = the image in (re-read from L2 by the panels that
+// share its rows) and out once.
+#include "common.h"
+#include "blur_panel.h"
+#include <algorithm>
+
+namespace {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef float floatx3 __attribute__((ext_vector_type(3)));
+constexpr int kPad = 64;            // zeros on either side of the taps in the LDS table
+constexpr int kDepth = 8;           // pass-1 loads in flight per wave
+constexpr int kStagePitch = 100;   // floats per staged output row (96 + 4: float4 rows, 16-byte aligned)
+
+struct PanelParams {
+  const float* x;
+  float* y;
+  const float* taps;
+  int B, H, W, T, nrb;
+  unsigned char order[16];          // row blocks, longest band first
+};
+
+__global__ __launch_bounds__(512) void blur_panel_kernel(const PanelParams p) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, kk = lane >> 5;
+  const int W = p.W, H = p.H, Q = 3 * W, pitch = Q + 1, T = p.T, half = T >> 1;
+  float* Ys = lds;                                  // [32][pitch]
+  float* tz = lds + 32 * pitch;                     // [kPad zeros][T taps][kPad zeros]
+  // (image, row block): the first half of the grid takes the long-band blocks, the second half the short ones, image-major in
+  // both, so that workgroups w and w + gridDim / 2 -- the pair a CU runs when the grid is two residency rounds -- add up evenly
+  int img, rb;
+  {
+    const int nrb = p.nrb, hb = nrb >> 1, w = blockIdx.x, halfgrid = (int)gridDim.x >> 1;
+    if (hb > 0 && (nrb & 1) == 0) {
+      const int second = w >= halfgrid, u = second ? w - halfgrid : w;
+      img = u / hb;
+      rb = p.order[second * hb + (u - img * hb)];
+    } else {
+      img = w / nrb;
+      rb = w - img * nrb;
+    }
+  }
+  const int r0 = 32 * rb;
+  floatx16 acc[3];
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+
+  // ---------------------------------------------------------------- pass 1: Y = T_H * X, B operand straight from global memory
+  {
+    const int k0 = max(0, r0 - half) & ~1, k1 = min(H, r0 + 32 + half);
+#if defined(BG_DIAG) && defined(PANEL_NO_P1)
+    const int K1 = 0, NG = 0;
+    (void)k1;
+#else
+    const int K1 = (k1 - k0 + 1) >> 1, NG = (K1 + kDepth - 1) / kDepth;
+#endif
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)img * H * Q), 0, H * Q * 4, 0x00020000);
+    // lane (li, kk): row k0 + 2s + kk, floats 3 * (32 * wave + li) .. + 2;  rows >= H lie past the descriptor's range: zeros
+    unsigned off = (unsigned)(((k0 + kk) * W + 32 * wave + li) * 12);
+    const unsigned dstep = (unsigned)(2 * W * 12);
+    const float* ta = tz + kPad + half + k0 + kk - r0 - li;            // + 2s
+    floatx3 pf[kDepth];
+#pragma unroll
+    for (int j = 0; j < kDepth; ++j) {
+      pf[j] = __builtin_bit_cast(floatx3, __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0));
+      off += dstep;
+    }
+    // the tap table goes up while the first eight loads are in flight
+    for (int j = tid; j < T + 2 * kPad; j += blockDim.x) tz[j] = (j >= kPad && j < kPad + T) ? p.taps[j - kPad] : 0.f;
+    __syncthreads();
+    float a_cur = ta[0];
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int j = 0; j < kDepth; ++j) {
+        const float a = a_cur;
+        a_cur = ta[2 * (g * kDepth + j + 1)];                          // next k-pair's Toeplitz fragment (zero past the band)
+        const floatx3 b = pf[j];
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.x, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc[2], 0, 0, 0);
+#if !(defined(BG_DIAG) && defined(PANEL_NO_LOADS))
+        pf[j] = __builtin_bit_cast(floatx3, __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0));
+#endif
+        off += dstep;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    // accumulator register i of lane (li, kk): row (i & 3) + 8 (i >> 2) + 4 kk, column (pixel 32 wave + li, channel c)
+    float* yo = Ys + (4 * kk) * pitch + (32 * wave + li) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) yo[((i & 3) + 8 * (i >> 2)) * pitch + c] = acc[c][i];
+  }
+  __syncthreads();
+
+  // ---------------------------------------------------------------- pass 2: Z^T = T_W * Y^T per channel, operands from LDS
+  {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
+    const int n0 = 32 * wave;
+    const int c0 = max(0, n0 - half) & ~1, c1 = min(W, n0 + 32 + half);
+#if defined(BG_DIAG) && defined(PANEL_NO_P2)
+    const int K2 = 0;
+    (void)c1;
+#else
+    const int K2 = (c1 - c0 + 1) >> 1;
+#endif
+    const float* ta = tz + kPad + half + c0 + kk - n0 - li;            // + 2s : T_W[x = n0 + li][x' = c0 + 2s + kk]
+    const float* yb = Ys + li * pitch + (c0 + kk) * 3;                 // + 6s (+ c): Y[r = li][x', c]
+    // two register sets, filled one k-pair ahead of the MFMAs that read them (no rotation moves, no multiply in the loop: a
+    // first version copied the prefetched set into the current one behind an lgkmcnt(0) at the end of every iteration and took
+    // 34 us for the 26 us of MFMAs this pass issues at the clock it runs at)
+    float aA = ta[0], bA0 = yb[0], bA1 = yb[1], bA2 = yb[2], aB = 0.f, bB0 = 0.f, bB1 = 0.f, bB2 = 0.f;
+    int s = 0;
+    for (; s + 2 <= K2; s += 2) {
+      aB = ta[2]; bB0 = yb[6]; bB1 = yb[7]; bB2 = yb[8];                 // pair s + 1 (exists: s + 2 <= K2)
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA2, acc[2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int adv = s + 2 < K2 ? 12 : 6;                              // pair s + 2, or pair s + 1 again when it is the last
+      aA = ta[4]; bA0 = yb[adv]; bA1 = yb[adv + 1]; bA2 = yb[adv + 2];  // the tap table reads zeros past the band
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB, bB0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB, bB1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB, bB2, acc[2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ta += 4;
+      yb += 12;
+    }
+    if (s < K2) {
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA2, acc[2], 0, 0, 0);
+    }
+    // register i of lane (li, kk): pixel n0 + (i & 3) + 8 (i >> 2) + 4 kk of output row r0 + li: 4 pixels x RGB = 12 contiguous
+    // floats.  Stored straight from there every float4 store instruction touched 64 different cache lines (a lane = a row, rows
+    // 3 KB apart): 17 of the kernel's 90 us at 143 taps.  So the wave's 32 x 96 tile goes through a PRIVATE LDS slab, 16 rows at
+    // a time, and leaves with consecutive lanes on consecutive 16 bytes of one row (24 lanes = the tile's 384 contiguous bytes).
+    float* stage = tz + ((T + 2 * kPad + 3) & ~3) + wave * (16 * kStagePitch);
+    float* zt = p.y + ((size_t)img * H + r0) * Q + (size_t)n0 * 3;
+#pragma unroll
+    for (int hrow = 0; hrow < 2; ++hrow) {
+      if ((li >> 4) == hrow) {
+        float* so = stage + (li & 15) * kStagePitch + 4 * kk * 3;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          float4 v0, v1, v2;
+          v0.x = acc[0][4 * g + 0]; v0.y = acc[1][4 * g + 0]; v0.z = acc[2][4 * g + 0]; v0.w = acc[0][4 * g + 1];
+          v1.x = acc[1][4 * g + 1]; v1.y = acc[2][4 * g + 1]; v1.z = acc[0][4 * g + 2]; v1.w = acc[1][4 * g + 2];
+          v2.x = acc[2][4 * g + 2]; v2.y = acc[0][4 * g + 3]; v2.z = acc[1][4 * g + 3]; v2.w = acc[2][4 * g + 3];
+          float4* d = reinterpret_cast<float4*>(so + 8 * g * 3);
+          d[0] = v0; d[1] = v1; d[2] = v2;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+      for (int it = 0; it < 6; ++it) {                       // 16 rows x 24 float4 = 384 = 6 per lane
+        const int e = it * 64 + lane, row = e / 24, f4 = e - row * 24;
+        const float4 v = *reinterpret_cast<const float4*>(stage + row * kStagePitch + 4 * f4);
+#if defined(BG_DIAG) && defined(PANEL_NO_STORE)
+        if (v.x == 123.456f)                                  // never true: keeps the data flow, drops the store traffic
+#endif
+        *reinterpret_cast<float4*>(zt + (size_t)(16 * hrow + row) * Q + 4 * f4) = v;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
+}
+
+void band_ranges(int n, int half, int rb, int* lo, int* hi) {
+  *lo = std::max(0, 32 * rb - half) & ~1;
+  *hi = std::min(n, 32 * rb + 32 + half);
+}
+
+}  // namespace
+
+namespace bg {
+
+bool blur_panel_ok(int B, int H, int W, int C, int n_taps) {
+  if (C != 3 || W % 32 || H % 32 || W > 256 || H > 512 || W < 32 || B <= 0) return false;
+  if (n_taps < 3 || !(n_taps & 1) || n_taps > 1023) return false;
+  return blur_panel_lds_bytes(W, n_taps) <= 160 * 1024 - 512;
+}
+
+size_t blur_panel_lds_bytes(int W, int n_taps) {
+  // the pass-1 result, the tap table, one 16-row staging slab per wave for the coalesced copy-out
+  return ((size_t)32 * (3 * W + 1) + ((n_taps + 2 * kPad + 3) & ~3) + (size_t)(W / 32) * 16 * kStagePitch + 4) * sizeof(float);
+}
+
+// MFMA flops the launch issues: 3 tiles x (k-pairs of pass 1, padded to groups of kDepth, + k-pairs of pass 2) per wave
+double blur_panel_exec_flops(int B, int H, int W, int n_taps) {
+  const int half = n_taps >> 1;
+  double pairs = 0;
+  for (int rb = 0; rb < H / 32; ++rb) {
+    int lo, hi;
+    band_ranges(H, half, rb, &lo, &hi);
+    const int K1 = (hi - lo + 1) / 2;
+    pairs += (double)((K1 + kDepth - 1) / kDepth * kDepth) * (W / 32);
+    for (int j = 0; j < W / 32; ++j) {
+      band_ranges(W, half, j, &lo, &hi);
+      pairs += (hi - lo + 1) / 2;
+    }
+  }
+  return (double)B * pairs * 3.0 * 2.0 * 32 * 32 * 2;
+}
+
+int blur_panel_launch(const float* x, float* y, int B, int H, int W, const float* taps_d, int n_taps, hipStream_t s) {
+  PanelParams p;
+  memset(&p, 0, sizeof p);
+  p.x = x; p.y = y; p.taps = taps_d; p.B = B; p.H = H; p.W = W; p.T = n_taps; p.nrb = H / 32;
+  int idx[16], cost[16];
+  for (int rb = 0; rb < p.nrb; ++rb) {
+    int lo, hi;
+    band_ranges(H, n_taps >> 1, rb, &lo, &hi);
+    idx[rb] = rb;
+    cost[rb] = hi - lo;
+  }
+  std::stable_sort(idx, idx + p.nrb, [&](int a, int b) { return cost[a] > cost[b]; });
+  // second half reversed: the longest band of the first half shares a CU with the shortest of the second
+  const int hb = p.nrb / 2;
+  for (int i = 0; i < hb; ++i) p.order[i] = (unsigned char)idx[i];
+  for (int i = hb; i < p.nrb; ++i) p.order[i] = (unsigned char)idx[p.nrb - 1 - (i - hb)];
+  const size_t lds = blur_panel_lds_bytes(W, n_taps);
+  BG_LDS_ATTR_ONCE(blur_panel_kernel, 160 * 1024, "blur_panel");
+  bg::launch(blur_panel_kernel, dim3((unsigned)(B * p.nrb)), dim3((unsigned)(64 * (W / 32))), lds, s, p);
+  return BG_OK;
+}
+
+}  // namespace bg

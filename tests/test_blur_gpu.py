@@ -75,6 +75,23 @@ def test_small_image_kernels_row_blocks_and_whole_image(shape, std, monkeypatch)
     np.testing.assert_allclose(y0, ref, rtol=POINT_RTOL, atol=POINT_ATOL * 4)
 
 
+@pytest.mark.parametrize("shape,std", [((3, 96, 224, 3), 15.0), ((5, 256, 128, 3), 30.0), ((2, 160, 256, 3), 12.0), ((9, 128, 96, 3), 23.5),
+                                       ((2, 256, 256, 3), 23.5), ((2, 256, 256, 3), 42.34), ((1, 512, 64, 3), 20.0), ((4, 128, 128, 3), 11.2)])
+def test_wide_tap_panel_kernel(shape, std, monkeypatch):
+    """blur_panel_kernel (> 65 taps, RGB, 32-row panels, both passes in one launch, the pass-1 result in LDS): odd and even panel
+    counts, non-square images, panels whose band is clipped on one side / both sides / not at all, bands wider than the image --
+    against the float64 oracle, and against the two-launch band passes it replaces (BG_BLUR_NO_PANEL=1)."""
+    x = np.random.default_rng(5).uniform(-1, 1, size=shape).astype(np.float32)
+    assert O.blur_policy(std, shape[1], shape[2])[2] >= 67
+    ref = O.blur_images(x.astype(np.float64), std)
+    y, _ = _run(x, std)
+    np.testing.assert_allclose(y, ref, rtol=POINT_RTOL, atol=POINT_ATOL * 4)
+    monkeypatch.setenv("BG_BLUR_NO_PANEL", "1")
+    y0, _ = _run(x, std)
+    np.testing.assert_allclose(y0, ref, rtol=POINT_RTOL, atol=POINT_ATOL * 4)
+    np.testing.assert_allclose(y, y0, rtol=2e-5, atol=2e-6)
+
+
 def _random_blur_cases(n, seed):
     rng = np.random.default_rng(seed)
     out = []
@@ -137,7 +154,7 @@ def test_blur_properties_c4_c5_sizes(shape, std):
     ks, se, nt = ops.blur_policy(std, H, W)
     taps = torch.tensor(ops.gauss_kernel_1d(se, ks), device="cuda")
     tmp = torch.empty(shape, device="cuda")
-    assert ops.blur_workspace_bytes(B, H, W, C, nt) == (0 if nt <= 65 else tmp.numel() * 4)   # <= 65 taps: fused strips, no scratch image
+    assert ops.blur_workspace_bytes(B, H, W, C, nt) == 0          # <= 65 taps: fused strips; above: 32-row panels -- no scratch image either way
     x = torch.rand(shape, device="cuda") * 2 - 1
     y = torch.rand(shape, device="cuda") * 2 - 1
     bl = lambda t: ops.blur_nhwc(t.contiguous(), torch.empty_like(t), taps, nt, tmp)
