@@ -197,7 +197,7 @@ def bench_blur(args):
     for name, ms, fl, by, ex in recs:
         k = kern.setdefault(name, [0, 0.0])
         k[0] += 1; k[1] += ms
-        exec_fl += ex if name.startswith("blur_band") else 0.0
+        exec_fl += ex if name.startswith(("blur_band", "blur_panel")) else 0.0
     total_ms = sum(k[1] for k in kern.values())
     per_app_ms = total_ms / (3 * apps)
     ach = alg_bytes / (per_app_ms * 1e-3) / 1e9
@@ -208,8 +208,9 @@ def bench_blur(args):
             "launches_per_application": len(recs) // (3 * apps), "avg_application_ms": round(per_app_ms, 5),
             "kernels_ms_per_application": {n: round(k[1] / (3 * apps), 5) for n, k in kern.items()}}
     if exec_fl > 0:
-        # above 65 taps the two transposing band passes run the banded Toeplitz product on the fp32 matrix pipe and THAT is the
-        # binding roof: the flops the passes issue (every 32x32x2 MFMA of the bands, image-clipped) over their own durations.
+        # above 65 taps the banded Toeplitz products (both passes of the 32-row panel kernel in one launch; the two transposing
+        # band passes for other channel counts) run on the fp32 matrix pipe and THAT is the binding roof: the flops they issue
+        # (every 32x32x2 MFMA of the bands, image-clipped) over their own durations.
         # The HBM view of the same launches stays in the object as "hbm".
         tf = exec_fl / (total_ms * 1e-3) / 1e12
         hbm_view = {k: roof[k] for k in ("achieved", "peak", "unit", "frac")}

@@ -1722,8 +1722,10 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
       int live[32], idx[32];
       for (int t = 0; t < ksize * ksize; ++t) {
         const int dyk = t / ksize - p.pt, dxk = t % ksize - p.pl;
-        const int oh_lo = std::max(0, (-dyk + stride - 1) / stride), oh_hi = std::min(p.Ho - 1, (H - 1 - dyk) / stride);
-        const int ow_lo = std::max(0, (-dxk + stride - 1) / stride), ow_hi = std::min(p.Wo - 1, (W - 1 - dxk) / stride);
+        // a tap that lies wholly outside a tiny map has H - 1 - dyk < 0: truncating division would give 0 instead of -1
+        auto floordiv = [](int a, int b) { return a >= 0 ? a / b : -((-a + b - 1) / b); };
+        const int oh_lo = std::max(0, (-dyk + stride - 1) / stride), oh_hi = std::min(p.Ho - 1, floordiv(H - 1 - dyk, stride));
+        const int ow_lo = std::max(0, (-dxk + stride - 1) / stride), ow_hi = std::min(p.Wo - 1, floordiv(W - 1 - dxk, stride));
         live[t] = std::max(0, oh_hi - oh_lo + 1) * std::max(0, ow_hi - ow_lo + 1);
         idx[t] = t;
       }

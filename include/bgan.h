@@ -100,7 +100,9 @@ int bg_blur3_lerp_nhwc_f32(const float* f, const float* r, const float* alpha_b,
 typedef enum {
   BG_EPI_NONE = 0,        /* y = acc (+ bias)                                                   */
   BG_EPI_BIAS_LRELU = 1,  /* y = lrelu(acc + bias); then y *= keep ? scale : 0 when keep != NULL */
-  BG_EPI_MUL_GRAD = 2,    /* y = acc * (ref > 0 ? 1 : alpha) [* keep ? scale : 0]               */
+  BG_EPI_MUL_GRAD = 2,    /* y = acc * (ref > 0 ? 1 : alpha) [* keep ? scale : 0].  `ref` MAY ALIAS the output (the penalty's
+                           * linearised forward overwrites the activations whose signs it consumes): every kernel reads
+                           * ref[i] in the thread that stores y[i], before that store                      */
   BG_EPI_TANH = 3,        /* y = tanh(acc + bias)                                               */
   BG_EPI_AFFINE_LRELU = 4 /* y = lrelu(acc * ref[c] + bias[c]): inference BatchNormalization folded (bg_bn_fold_f32), ref = per-channel scale */
 } bg_epi_mode;
@@ -298,6 +300,9 @@ int bg_gstep(bg_program* p, void* stream);      /* wgan.py:159-172 as recorded *
 typedef struct bg_comm bg_comm;
 int bg_comm_unique_id(unsigned char* id_out);
 int bg_comm_init(bg_comm** out, int rank, int nranks, const unsigned char* id_bytes);
+/* One communicator may be driven from TWO streams (the step issues its bucketed gradient reductions on a private stream and the
+ * SyncBN statistics exchanges in line on the compute stream): the calls are then ordered by RCCL in ISSUE order on the host, so
+ * every rank must issue them in the same order (the step program guarantees it); a host that cannot should keep to one stream. */
 int bg_allreduce_sum_f32(bg_comm* comm, float* buf_d, size_t n, void* stream);
 int bg_comm_destroy(bg_comm* comm);
 

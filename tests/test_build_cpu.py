@@ -77,3 +77,47 @@ def test_band_kernel_accumulator_registers_are_only_touched_by_hand(blur_isa):
         assert spills and all(int(s) == 0 for s in spills), (m.group(1), spills)
     scratch = re.findall(r"\.set (\S*blur_band_t_kernel\S*)\.private_seg_size, (\d+)", blur_isa)
     assert scratch and all(int(v) == 0 for _, v in scratch), scratch
+
+
+def _isa(tmp_path_factory, src):
+    out = tmp_path_factory.mktemp("isa") / (src + ".s")
+    subprocess.run([HIPCC, *FLAGS, "-S", "--cuda-device-only", os.path.join(ROOT, "blurred-gan_amd", "csrc", src), "-o", str(out)],
+                   check=True, capture_output=True)
+    return out.read_text()
+
+
+def _resources(isa, pattern):
+    """{kernel: (vgpr spills, sgpr spills, scratch bytes)} of the kernels whose mangled name contains `pattern`."""
+    res = {}
+    for m in re.finditer(r"\.name:\s+(\S*" + pattern + r"\S*)\n(.*?)\.wavefront_size", isa, flags=re.S):
+        body = m.group(2)
+        g = lambda key: int(re.search(r"\." + key + r":\s+(\d+)", body).group(1))
+        res[m.group(1)] = (g("vgpr_spill_count"), g("sgpr_spill_count"), g("private_segment_fixed_size"))
+    return res
+
+
+def test_hot_kernels_do_not_spill(tmp_path_factory):
+    """the statistics variant of the 64 x 64 gather-GEMM tile must not be forced to four waves per SIMD (it would
+    spill); and the two kernels of round 4 that live on a tight register budget -- the strip-resident filter gradient (208
+    accumulator registers + fragments) and the panel blur -- stay free of spills and scratch."""
+    for src, pattern, least in (("conv_igemm.hip", "conv_igemm_kernel", 6), ("conv_wgrad.hip", "conv_wgrad_strip_kernel", 3),
+                                ("blur_panel.hip", "blur_panel_kernel", 1)):
+        isa = _isa(tmp_path_factory, src)
+        res = _resources(isa, pattern)
+        assert len(res) >= least, (src, list(res))
+        # SGPR spills go to VGPR lanes (v_writelane), not to memory: the wide tiles carry a few; what must stay zero is VGPR spills and scratch
+        assert all(v[0] == 0 and v[2] == 0 for v in res.values()), {k: v for k, v in res.items() if v[0] or v[2]}
+        if pattern == "conv_wgrad_strip_kernel":
+            # the k loop's order is pinned by volatile asm: between two MFMAs of a pair sits at most ONE other memory instruction
+            body = re.search(r"^_ZN\S*conv_wgrad_strip_kernelILi5\S*:[^\n]*\n(.*?)s_endpgm", isa, flags=re.S | re.M).group(1)
+            ops = [ln.split()[0] for ln in body.splitlines() if ln.strip() and not ln.strip().startswith((";", "."))]
+            runs, cur = [], 0
+            seen_mfma = False
+            for op in ops:
+                if op.startswith("v_mfma"):
+                    if seen_mfma:
+                        runs.append(cur)
+                    seen_mfma, cur = True, 0
+                elif op.startswith(("ds_read", "ds_write", "buffer_load")) and seen_mfma:
+                    cur += 1
+            assert len(runs) > 400 and sorted(runs)[int(len(runs) * 0.9)] <= 1, sorted(runs)[-20:]

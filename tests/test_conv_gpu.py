@@ -134,6 +134,34 @@ def test_epilogues():
     np.testing.assert_allclose(dx.cpu().numpy(), exp, rtol=1e-4, atol=2 * conv_tol(25 * Co, np.abs(dxr).max()))
 
 
+@pytest.mark.parametrize("B,H,W,Ci,Co,s", [
+    (4, 16, 16, 32, 64, 2),       # gather-GEMM, float4 epilogue
+    (130, 4, 4, 128, 256, 2),     # position-major tiles + split-K (slab reduce writes the output)
+    (3, 64, 64, 16, 32, 2),       # row-staged 16-channel forward
+    (2, 16, 16, 3, 32, 2),        # thin-K row kernel
+    (2, 9, 7, 20, 12, 2),         # unaligned: direct kernel
+    (2, 16, 16, 32, 3, 1),        # thin-N row kernel
+])
+def test_mul_grad_epilogue_with_ref_aliasing_the_output(B, H, W, Ci, Co, s):
+    """include/bgan.h BG_EPI_MUL_GRAD: `ref` may alias the output -- the penalty's linearised forward (engine.Net.gp_second_order_merged)
+    overwrites the activation rows whose signs it consumes.  Every forward kernel family must read ref[i] in the thread that stores
+    y[i], before that store: in place == out of place, bit for bit."""
+    from blurred_gan_amd import ops
+    from blurred_gan_amd._lib import EPI_MUL_GRAD
+    x, w, dy = _data(B, H, W, Ci, Co, s, seed=21)
+    wT = dev(np.transpose(w, (0, 1, 3, 2)))
+    Ho, Wo = -(-H // s), -(-W // s)
+    act = torch.randn(B, Ho, Wo, Co, device="cuda")
+    nb = ops.conv2d_splitk_workspace_bytes(False, B, H, W, Ci, Co, 5, s)
+    ws = torch.empty(nb // 4 + 4, device="cuda") if nb else None
+    sep = ops.conv2d_fwd(dev(x), wT, torch.empty_like(act), 5, s, ops.epilogue(EPI_MUL_GRAD, ref=act.clone(), alpha=0.3, ws=ws))
+    inplace = act.clone()
+    ops.conv2d_fwd(dev(x), wT, inplace, 5, s, ops.epilogue(EPI_MUL_GRAD, ref=inplace, alpha=0.3, ws=ws))
+    assert torch.equal(sep, inplace)
+    ref = O.conv2d_fwd(x, w, s) * np.where(act.cpu().numpy() > 0, 1.0, 0.3)
+    np.testing.assert_allclose(sep.cpu().numpy(), ref, rtol=1e-4, atol=2 * conv_tol(25 * Ci, np.abs(ref).max()))
+
+
 def test_c16_epilogues():
     """The row-staged 16-channel data gradient with the critic's fused LeakyReLU'/dropout product, mask on the leading samples only."""
     from blurred_gan_amd import ops
