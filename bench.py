@@ -360,7 +360,7 @@ def main():
         if kern and args.kernels_out:
             table = [{"kernel": n, "launches_per_step": k[0] / 2, "ms_per_step": round(k[1] / 2, 5),
                       "tflops": round(k[2] / (k[1] * 1e-3) / 1e12, 2) if k[2] else None} for n, k in sorted(kern.items(), key=lambda kv: -kv[1][1])]
-            seq = [{"kernel": n, "us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 3)} for n, ms, fl, _, _ in recs[:len(recs) // 2]]
+            seq = [{"kernel": n, "us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 3), "alg_mb": round(by / 1e6, 3)} for n, ms, fl, by, _ in recs[:len(recs) // 2]]
             with open(args.kernels_out, "w") as f:
                 json.dump({"ms_per_step_sum": round(sum(k[1] for k in kern.values()) / 2, 4), "kernels": table, "sequence": seq}, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:

@@ -1736,13 +1736,15 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
   }
   p.out = slabs ? static_cast<float*>(ws_d) : dw;
   const double flops = 2.0 * p.M * (double)nout;
+  // algorithmic bytes: x and dy read once, dw written once (read too when it is accumulated into)
+  const double abytes = 4.0 * ((double)B * H * W * Cin + (double)p.M * Cout + (double)nout * (beta != 0.f ? 2 : 1));
   int rc;
   if (pl.mode == 0) {
-    bg::Launch L(stream, "conv_wgrad_direct", flops, 0);
+    bg::Launch L(stream, "conv_wgrad_direct", flops, abytes);
     bg::launch(wgrad_direct_kernel, dim3(bg::cdiv(nout, 256), pl.ksplit), dim3(256), 0, L.s, p);
     rc = L.done("wgrad_direct_kernel");
   } else if (pl.mode == 33) {
-    bg::Launch L(stream, "conv_wgrad_mfma", flops, 0);
+    bg::Launch L(stream, "conv_wgrad_mfma", flops, abytes);
     const int lgwo = p.Wo == 32 ? 5 : (p.Wo == 16 ? 4 : 3);
     const int spi = p.Ho / (64 / p.Wo), nstrips = B * spi, ntile = pl.tiles_m * pl.tiles_n;
     BG_LDS_ATTR_ONCE_V(conv_wgrad_strip_kernel<5>, StripGeom<5>::lds_bytes);
@@ -1754,7 +1756,7 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     else bg::launch((conv_wgrad_strip_kernel<3>), grid, dim3(256), StripGeom<3>::lds_bytes, L.s, p, nstrips, spi, pl.chunk, ntile);
     rc = L.done("conv_wgrad_strip_kernel");
   } else if (pl.mode == 32) {
-    bg::Launch L(stream, "conv_wgrad_c16", flops, 0);
+    bg::Launch L(stream, "conv_wgrad_c16", flops, abytes);
     const int spi = p.Ho / 2, nstrips = B * spi;
     const size_t lds = std::max((size_t)2 * kC16Rows * 2 * (p.Wo + 2) * 16, (size_t)25 * 2 * 4 * 64) * sizeof(float);
     BG_LDS_ATTR_ONCE_V(conv_wgrad_c16_kernel<64>, 150 * 1024);
@@ -1763,7 +1765,7 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     else bg::launch((conv_wgrad_c16_kernel<32>), dim3(pl.ksplit), dim3(256), lds, L.s, p, nstrips, spi);
     rc = L.done("conv_wgrad_c16_kernel");
   } else if (pl.mode == 31) {
-    bg::Launch L(stream, "conv_wgrad_mfma_thin_ci", flops, 0);
+    bg::Launch L(stream, "conv_wgrad_mfma_thin_ci", flops, abytes);
     const int rb = stride == 2 ? 8 : 16;
     const int bpi = (int)bg::cdiv(p.Ho, rb), nblocks = B * bpi;
     const int nt = Cout / 16;
@@ -1775,7 +1777,7 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
 #undef BG_TI
     rc = L.done("conv_wgrad_thin_ci_kernel");
   } else if (pl.mode == 30) {
-    bg::Launch L(stream, "conv_wgrad_mfma_thin_co", flops, 0);
+    bg::Launch L(stream, "conv_wgrad_mfma_thin_co", flops, abytes);
     const int bpi = (int)bg::cdiv(H, kTcRows), nblocks = B * bpi;
     const int mt = Cin / 16;
     const size_t lds = std::max((size_t)(kTcRows + ksize - 1) * (W * Cout + 2 * kTcHalo), (size_t)4 * ksize * mt * 4 * 64) * sizeof(float);
@@ -1787,7 +1789,7 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     rc = L.done("conv_wgrad_thin_co_kernel");
   } else {
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.taps_in_grid == 1 ? ksize * ksize : (pl.taps_in_grid == 2 ? ksize : 1), pl.ksplit);
-    bg::Launch L(stream, pl.mode >= 20 ? "conv_wgrad_mfma_thin_co" : (pl.mode >= 10 ? "conv_wgrad_mfma_thin_ci" : "conv_wgrad_mfma"), flops, 0);
+    bg::Launch L(stream, pl.mode >= 20 ? "conv_wgrad_mfma_thin_co" : (pl.mode >= 10 ? "conv_wgrad_mfma_thin_ci" : "conv_wgrad_mfma"), flops, abytes);
     const dim3 grid1((unsigned)(grid.x * grid.y * grid.z));      // v3 / tg kernels decode (tile, tap, split) themselves
     switch (pl.mode) {
 #define BG_V3(BMv, BNv, BKv, WMv, WNv, WKv)                                                                               \

@@ -360,6 +360,33 @@ __device__ inline float4 load4_param(const float* __restrict__ p, int c, bool al
 __device__ inline bool ptr_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // y = lrelu(gamma*(x-mean)*inv + beta); mean/inv either saved batch stats or derived from moving stats
+// bn_finalize_sums_kernel + bn_apply_kernel in one launch (SyncBN forward: conv -> sums -> all-reduce -> THIS): every thread derives
+// mean / inv of its channels from the (all-reduced) sums with the expressions of bn_finalize_sums_kernel, so y is bit-identical to
+// the two launches; the threads that hold the first row (e < C) also leave save_mean / save_inv and update the moving statistics.
+__global__ __launch_bounds__(kT) void bn_finalize_apply_kernel(const float* __restrict__ sums, int M, const float* __restrict__ x,
+                                                               float* __restrict__ y, size_t total, int C, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* save_mean, float* save_inv,
+                                                               float* moving_mean, float* moving_var, float eps, float momentum,
+                                                               int unbiased, float alpha) {
+  for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < total; e += (size_t)gridDim.x * kT) {
+    const int c = (int)(e % C);
+    const float mean = sums[c] / (float)M;
+    const float var = fmaxf(sums[C + c] / (float)M - mean * mean, 0.f);
+    const float inv = 1.0f / sqrtf(var + eps);
+    if (e < (size_t)C) {
+      save_mean[c] = mean;
+      save_inv[c] = inv;
+      if (moving_mean) {
+        const float vu = unbiased ? var * ((float)M / (float)max(M - 1, 1)) : var;
+        moving_mean[c] = moving_mean[c] * momentum + mean * (1.f - momentum);
+        moving_var[c] = moving_var[c] * momentum + vu * (1.f - momentum);
+      }
+    }
+    const float v = gamma[c] * ((x[e] - mean) * inv) + beta[c];
+    y[e] = v > 0.f ? v : alpha * v;
+  }
+}
+
 __global__ __launch_bounds__(kT) void bn_apply_kernel(const float* __restrict__ x, float* __restrict__ y, size_t total, int C,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ mean, const float* __restrict__ inv_or_var,
@@ -892,6 +919,18 @@ int bg_bn_apply_f32(const float* x, float* y, int M, int C, const float* gamma, 
   bg::Launch L(stream, "bn_apply_lrelu", 0, 8.0 * total);
   bg::launch(bn_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, x, y, total, C, gamma, beta, mean, inv, 0, 0.f, lrelu_alpha);
   return L.done("bn_apply_kernel");
+}
+
+int bg_bn_finalize_apply_f32(const float* sums_d, int M_total, const float* x, float* y, int M, int C, const float* gamma, const float* beta,
+                             float* save_mean, float* save_inv, float* moving_mean, float* moving_var, float eps, float momentum,
+                             int unbiased, float lrelu_alpha, void* stream) {
+  BG_REQUIRE(sums_d && x && y && gamma && beta && save_mean && save_inv, BG_ERR_NULL, "bg_bn_finalize_apply_f32: null pointer");
+  BG_REQUIRE(M > 0 && C > 0 && M_total >= M, BG_ERR_BAD_SHAPE, "bg_bn_finalize_apply_f32: M=%d M_total=%d C=%d", M, M_total, C);
+  const size_t total = (size_t)M * C;
+  bg::Launch L(stream, "bn_finalize_apply", 0, 8.0 * total);
+  bg::launch(bn_finalize_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, sums_d, M_total, x, y, total, C, gamma, beta, save_mean, save_inv,
+             moving_mean, moving_var, eps, momentum, unbiased, lrelu_alpha);
+  return L.done("bn_finalize_apply_kernel");
 }
 
 int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, int C, const float* save_mean,

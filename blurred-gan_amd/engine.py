@@ -344,7 +344,10 @@ class Net:
                     # training BatchNorm behind a bias-free conv: the MFMA kernel leaves the column sums of what it stores
                     # (one row per workgroup); at most one workgroup per 32 output rows and sub-pixel phase
                     stats = None
-                    if training and bias is None and self.fuse_bn_stats:
+                    # under SyncBN the statistics ride in the conv's epilogue (the separate statistics pass would be two more
+                    # launches on the forward critical path beside every exchange); single-device: opt-in, see __init__
+                    if training and bias is None and (self.fuse_bn_stats or (self.sync_bn and dist.collectives_active()
+                                                                           and not os.environ.get("BGAN_NO_FUSED_BN_STATS"))):
                         C = st.out_shape[-1]
                         stats = ctx.bn_partials(i, int(np.prod((B,) + st.out_shape[:-1])) // 32 + 64, C)
                     epi = self._epi(*geom, EPI_NONE, bias=bias, stats=stats)
@@ -374,9 +377,11 @@ class Net:
                         ws = self.workspace(ops._lib.load().bg_bn_workspace_bytes(M, C))
                         ops.bn_stats(tgt, M, C, sums, ws)
                     dist.all_reduce_sum_(sums)
-                    ops.bn_finalize(sums, M * dist.world_size(), C, ctx.mean[i], ctx.inv[i], bn.vars["moving_mean"],
-                                    bn.vars["moving_variance"], eps=bn.epsilon, momentum=bn.momentum, unbiased=(len(st.out_shape) == 3))
-                    ops.bn_apply(tgt, out, M, C, bn.vars["gamma"], bn.vars["beta"], ctx.mean[i], ctx.inv[i], lrelu_alpha=st.alpha)
+                    # finalize + apply in one launch: with the statistics out of the conv's epilogue the chain around the
+                    # exchange is two launches per layer (partials -> sums, this)
+                    ops.bn_finalize_apply(sums, M * dist.world_size(), tgt, out, M, C, bn.vars["gamma"], bn.vars["beta"], ctx.mean[i],
+                                          ctx.inv[i], bn.vars["moving_mean"], bn.vars["moving_variance"], eps=bn.epsilon,
+                                          momentum=bn.momentum, unbiased=(len(st.out_shape) == 3), lrelu_alpha=st.alpha)
                 elif training and stat_rows:
                     ops.bn_train_fwd_partials(ctx.bn_partials(i, stat_rows, C), stat_rows, tgt, out, M, C, bn.vars["gamma"], bn.vars["beta"],
                                               bn.vars["moving_mean"], bn.vars["moving_variance"], ctx.mean[i], ctx.inv[i], eps=bn.epsilon,

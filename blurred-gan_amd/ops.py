@@ -276,6 +276,14 @@ def bn_apply(x, y, M, Cc, gamma, beta, mean, inv, lrelu_alpha=LRELU_ALPHA):
     return y
 
 
+def bn_finalize_apply(sums, M_total, x, y, M, Cc, gamma, beta, save_mean, save_inv, moving_mean, moving_var, eps=1e-3, momentum=0.99,
+                      unbiased=True, lrelu_alpha=LRELU_ALPHA):
+    check(_lib.load().bg_bn_finalize_apply_f32(_ptr(sums), M_total, _ptr(x), _ptr(y), M, Cc, _ptr(gamma), _ptr(beta), _ptr(save_mean),
+                                               _ptr(save_inv), _ptr(moving_mean), _ptr(moving_var), eps, momentum, int(unbiased), lrelu_alpha,
+                                               _stream()), "bg_bn_finalize_apply_f32")
+    return y
+
+
 def bn_bwd_stats(dy, y, x, M, Cc, save_mean, save_inv, sums, ws, lrelu_alpha=LRELU_ALPHA):
     check(_lib.load().bg_bn_bwd_stats_f32(_ptr(dy), _ptr(y), _ptr(x), M, Cc, _ptr(save_mean), _ptr(save_inv), lrelu_alpha, _ptr(sums),
                                           _ptr(ws), ws.numel() * ws.element_size(), _stream()), "bg_bn_bwd_stats_f32")

@@ -189,6 +189,12 @@ int bg_bn_finalize_f32(const float* sums_d, int M_total, int C, float* save_mean
                        float* moving_var, float eps, float momentum, int unbiased, void* stream);
 int bg_bn_apply_f32(const float* x, float* y, int M, int C, const float* gamma, const float* beta, const float* mean,
                     const float* inv, float lrelu_alpha, void* stream);
+/* bg_bn_finalize_f32 + bg_bn_apply_f32 in ONE launch (same arithmetic, bit-identical y / saved / moving statistics): behind a conv
+ * that left its statistics in the epilogue (bg_epilogue.stats) the SyncBN forward chain is bg_bn_sums_from_partials -> all-reduce
+ * -> this, two launches per layer beside the exchange. */
+int bg_bn_finalize_apply_f32(const float* sums_d, int M_total, const float* x, float* y, int M, int C, const float* gamma,
+                             const float* beta, float* save_mean, float* save_inv, float* moving_mean, float* moving_var, float eps,
+                             float momentum, int unbiased, float lrelu_alpha, void* stream);
 /* training-mode BatchNormalization + LeakyReLU from statistics PARTIALS partial[nrows][2][C] (column sums, sums of squares) left
    by the producing conv (bg_epilogue.stats): finalize (+ moving statistics) and apply, no statistics pass over x */
 int bg_bn_train_fwd_partials(const float* partial_d, int nrows, const float* x, float* y, int M, int C, const float* gamma,

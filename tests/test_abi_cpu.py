@@ -67,7 +67,9 @@ def test_errors_are_statuses_not_crashes(lib):
     # workspace queries are pure host functions
     assert lib.bg_blur_workspace_bytes(4, 64, 64, 3, 31) == 0
     assert lib.bg_blur_workspace_bytes(4, 128, 128, 3, 31) == 0                     # fused strips: both passes in one launch
-    assert lib.bg_blur_workspace_bytes(4, 128, 128, 3, 129) == 4 * 128 * 128 * 3 * 4   # two band passes through a scratch image
+    assert lib.bg_blur_workspace_bytes(4, 128, 128, 3, 129) == 0                    # 32-row panels: both band passes in one launch
+    assert lib.bg_blur_workspace_bytes(4, 128, 128, 4, 129) == 4 * 128 * 128 * 4 * 4   # 4 channels: two band passes through a scratch image
+    assert lib.bg_blur3_lerp_supported(8, 64, 64, 3, 31) == 1 and lib.bg_blur3_lerp_supported(8, 128, 128, 3, 31) == 0
     assert lib.bg_conv2d_bwd_filter_workspace_bytes(256, 32, 32, 32, 64, 5, 2) > 0
 
 

@@ -3,6 +3,8 @@
 (FETCH_SIZE in one, WRITE_SIZE in the other; MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reads half of a wide coalesced
 stream -> doubled; both counters are in KiB).  The launches of the LAST step in each pass are matched, in order, with the
 tag sequence bench.py wrote (--kernels-out), which separates forward from data-gradient launches of the same kernel symbol.
+Also writes <out.json>.wgrad.md: every filter-gradient launch of the step (matched the same way) with its ALGORITHMIC bytes (x and
+dy read once, dw written once: the figure the library records) beside the counted ones and their ratio.
 Usage: pmc_traffic.py <fetch_dir> <write_dir> <kernels.json> <out.json>"""
 import csv
 import glob
@@ -42,6 +44,22 @@ def main():
                    "hbm_bytes_per_launch": (sum(d["fetch"]) + sum(d["write"])) / n}
     json.dump(outd, open(out, "w"), indent=1)
     print(json.dumps(outd, indent=1))
+    # ---- filter gradients, launch by launch
+    full = json.load(open(kjson))["sequence"]
+    wtags = [e for e in full if e["kernel"].startswith("conv_wgrad") and "reduce" not in e["kernel"]]
+    isw = lambda n: "conv_wgrad" in n and "reduce" not in n
+    fd = [(n, v) for n, v in dispatches(fdir, "FETCH_SIZE") if isw(n)]
+    wd = [(n, v) for n, v in dispatches(wdir, "WRITE_SIZE") if isw(n)]
+    if wtags and len(fd) >= len(wtags) and len(wd) >= len(wtags):
+        fd, wd = fd[-len(wtags):], wd[-len(wtags):]
+        with open(out + ".wgrad.md", "w") as fh:
+            fh.write("| launch (step order) | kernel symbol | us | algorithmic MB | HBM-side MB (fetch x2 + write) | ratio |\n|---|---|---|---|---|---|\n")
+            for i, (e, (fn, fv), (_, wv)) in enumerate(zip(wtags, fd, wd)):
+                hbm = (fv * 2.0 + wv) * 1024.0 / 1e6
+                sym = fn.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
+                alg = e.get("alg_mb") or 0.0
+                fh.write(f"| {i} {e['kernel']} ({e['gflop']} GFLOP) | `{sym[:60]}` | {e['us']} | {alg:.1f} | {hbm:.1f} | {hbm / alg if alg else float('nan'):.2f} |\n")
+        print(open(out + ".wgrad.md").read())
 
 
 if __name__ == "__main__":
