@@ -14,8 +14,8 @@
 //                lane ends with 4 consecutive pixels x 3 channels of ONE output row = 12 contiguous floats -> three float4 stores,
 //                straight into the NHWC result (no transposed store, no scratch image).  Wave w owns the pixel tile [32w, 32w+32).
 // Both passes contract over the band only (rows / columns outside the image: the range is clipped; partial pairs: zero taps).
-// Workgroups are dealt so that the two a CU runs (512 for 64 images of 256 rows on 256 CUs) are one long-band and one short-band
-// panel (middle panels contract over 32 + T - 1 rows, border panels over fewer).
+// Workgroups are dealt so that the panels of an image share an XCD (its L2 serves their overlapping row ranges) and the two a CU
+// runs (512 for 64 images of 256 rows on 256 CUs) are one long-band and one short-band panel.
 // MFMA-bound: 2 * 3 * (K_H + K_W) / 2 MFMAs of 32x32x2 per wave; HBM traffic = the image in (re-read from L2 by the panels that
 // share its rows) and out once.
 #include "common.h"
@@ -45,18 +45,22 @@ __global__ __launch_bounds__(512) void blur_panel_kernel(const PanelParams p) {
   const int W = p.W, H = p.H, Q = 3 * W, pitch = Q + 1, T = p.T, half = T >> 1;
   float* Ys = lds;                                  // [32][pitch]
   float* tz = lds + 32 * pitch;                     // [kPad zeros][T taps][kPad zeros]
-  // (image, row block): the first half of the grid takes the long-band blocks, the second half the short ones, image-major in
-  // both, so that workgroups w and w + gridDim / 2 -- the pair a CU runs when the grid is two residency rounds -- add up evenly
+  // (image, row block).  The panels of an image re-read its rows (a 32-row panel contracts over up to 32 + T - 1 of them), so
+  // they must meet in ONE L2: workgroup w runs on XCD w % 8 (tools/probes/placement.hip), which therefore takes the images
+  // xcd, xcd + 8, ... whole, image after image (4 images = 32 workgroups = the XCD's CUs at one panel per CU).  Dealt round-robin
+  // the eight panels of an image sat on eight XCDs: L2 hit rate 0.15, 300 MB of HBM-side traffic per launch for a 50 MB image
+  // set (3.9 TB/s beside the MFMAs).  Within an image the panels go longest band first, and every second group of four images
+  // shortest first, so that the two panels a CU runs are one long and one short.
   int img, rb;
   {
-    const int nrb = p.nrb, hb = nrb >> 1, w = blockIdx.x, halfgrid = (int)gridDim.x >> 1;
-    if (hb > 0 && (nrb & 1) == 0) {
-      const int second = w >= halfgrid, u = second ? w - halfgrid : w;
-      img = u / hb;
-      rb = p.order[second * hb + (u - img * hb)];
+    const int nrb = p.nrb, w = blockIdx.x;
+    if ((p.B & 7) == 0) {
+      const int xcd = w & 7, j = w >> 3, il = j / nrb, k = j - il * nrb;
+      img = il * 8 + xcd;
+      rb = p.order[(il & 4) ? nrb - 1 - k : k];
     } else {
       img = w / nrb;
-      rb = w - img * nrb;
+      rb = p.order[w - img * nrb];
     }
   }
   const int r0 = 32 * rb;
@@ -248,10 +252,7 @@ int blur_panel_launch(const float* x, float* y, int B, int H, int W, const float
     cost[rb] = hi - lo;
   }
   std::stable_sort(idx, idx + p.nrb, [&](int a, int b) { return cost[a] > cost[b]; });
-  // second half reversed: the longest band of the first half shares a CU with the shortest of the second
-  const int hb = p.nrb / 2;
-  for (int i = 0; i < hb; ++i) p.order[i] = (unsigned char)idx[i];
-  for (int i = hb; i < p.nrb; ++i) p.order[i] = (unsigned char)idx[p.nrb - 1 - (i - hb)];
+  for (int i = 0; i < p.nrb; ++i) p.order[i] = (unsigned char)idx[i];
   const size_t lds = blur_panel_lds_bytes(W, n_taps);
   BG_LDS_ATTR_ONCE(blur_panel_kernel, 160 * 1024, "blur_panel");
   bg::launch(blur_panel_kernel, dim3((unsigned)(B * p.nrb)), dim3((unsigned)(64 * (W / 32))), lds, s, p);

@@ -9,8 +9,11 @@ import sys
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 path = os.path.join(root, "profiles", "hbm_traffic.json")
 d = json.load(open(path))
-src = "blurred-gan_amd/csrc/blur.hip"
-sha = hashlib.sha1(open(os.path.join(root, src), "rb").read()).hexdigest()[:16]
+srcs = ["blurred-gan_amd/csrc/blur.hip", "blurred-gan_amd/csrc/blur_panel.hip", "blurred-gan_amd/csrc/blur_panel.h"]
+h = hashlib.sha1()
+for s_ in srcs:
+    h.update(open(os.path.join(root, s_), "rb").read())
+sha = h.hexdigest()[:16]
 kernels = {}
 for arg in sys.argv[1:]:
     taps, f = arg.split("=")
@@ -25,6 +28,6 @@ for arg in sys.argv[1:]:
         e["l2_hit_rate"] = sum(hit) / len(hit)
     kernels[f"blur{taps}"] = e
 d["entries"] = [e for e in d["entries"] if e.get("arch") != "blur256"]
-d["entries"].append({"arch": "blur256", "batch": 64, "sources": [src], "sources_sha": sha, "kernels": kernels})
+d["entries"].append({"arch": "blur256", "batch": 64, "sources": srcs, "sources_sha": sha, "kernels": kernels})
 json.dump(d, open(path, "w"), indent=1)
 print(json.dumps(kernels, indent=1))
