@@ -108,6 +108,7 @@ __global__ __launch_bounds__(kFusedThreads) void blur_fused_kernel(const float* 
 // the W pass are conflict-free), Toeplitz fragments read from a zero-padded copy of the taps, result re-interleaved on the
 // way out.  HBM traffic == algorithmic (8*H*W*C bytes per image).
 // ------------------------------------------------------------------------------------------------
+typedef float floatx4 __attribute__((ext_vector_type(4)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 constexpr int kTzPad = 64;
 
@@ -205,22 +206,48 @@ __global__ __launch_bounds__(kMfmaBlurThreads) void blur_mfma_kernel(const float
 constexpr int kRowsThreads = 512;
 constexpr int kRowsBlock = 32;            // output rows per workgroup (one MFMA row block)
 
-struct RowsGeom { int Q, Wp, Qp, pitchY, pitchZ, xfloats, nb; size_t lds; };
+struct RowsGeom { int Q, Wp, Qp, pitchX, pitchY, pitchZ, xfloats, nb; size_t lds; };
+// LDS pitches of the three tiles, chosen against the 64 banks for the lane patterns of the 16 x 16 x 4 passes: X is read with
+// lanes (k = lane / 16, column = lane % 16) -> pitch = 16 (mod 64) puts the four k rows on four different bank quarters; Y is
+// written with (row = 4 * (lane / 16) + i, column = lane % 16) and read with (row = lane % 16, x' = lane / 16, stride C) ->
+// pitch = 4 (mod 64) makes both conflict-free for C <= 5; Z likewise and a multiple of 4 for the float4 copy out.
+__host__ __device__ inline int rows_pitch(int q, int r) { return q + ((r - q) & 63); }
 inline RowsGeom rows_geom(int H, int W, int C, int T) {
   RowsGeom g;
   const int half = T >> 1;
   g.Q = W * C;
   g.Wp = (W + 31) / 32 * 32;
   g.Qp = (g.Wp * C + 31) / 32 * 32;
-  g.pitchY = g.Qp + 1;                    // odd: the W pass reads Y with lanes along rows
-  g.pitchZ = g.Qp + 4;                    // float4 rows for the copy out
+  g.pitchX = rows_pitch(g.Qp, 16);
+  g.pitchY = rows_pitch(g.Qp, 4);
+  g.pitchZ = rows_pitch(g.Qp, 4);
   g.nb = (H + kRowsBlock - 1) / kRowsBlock;
   int rows = 0;
   for (int rb = 0; rb < g.nb; ++rb) rows = std::max(rows, std::min(H, rb * kRowsBlock + kRowsBlock + half) - std::max(0, rb * kRowsBlock - half));
-  rows = (rows + 1) & ~1;
-  g.xfloats = (std::max(rows * g.Qp, kRowsBlock * g.pitchZ) + 3) & ~3;
+  rows = (rows + 3) & ~3;                 // k-steps of 4 source rows (v_mfma_f32_16x16x4_f32)
+  g.xfloats = (std::max(rows * g.pitchX, kRowsBlock * g.pitchZ) + 3) & ~3;
   g.lds = ((size_t)g.xfloats + (((size_t)kRowsBlock * g.pitchY + 3) & ~(size_t)3) + T + 2 * kTzPad) * sizeof(float);
   return g;
+}
+
+// n (wave-uniform) k-steps of v_mfma_f32_16x16x4_f32 with both operands from LDS: a[4 i sa], b[4 i sb].  The reads of a run are
+// issued together and waited for once (a loop of read, wait, MFMA pays the LDS latency per step: 250 cycles per MFMA measured).
+template <int N>
+__device__ __forceinline__ floatx4 rows_steps(const float* a, int sa, const float* b, int sb, floatx4 acc) {
+  float av[N], bv[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) { av[i] = a[4 * i * sa]; bv[i] = b[4 * i * sb]; }
+#pragma unroll
+  for (int i = 0; i < N; ++i) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[i], acc, 0, 0, 0);
+  return acc;
+}
+__device__ __forceinline__ floatx4 rows_chain(const float* a, int sa, const float* b, int sb, int n, floatx4 acc) {
+  while (n >= 12) { acc = rows_steps<12>(a, sa, b, sb, acc); a += 48 * sa; b += 48 * sb; n -= 12; }
+  if (n >= 8) { acc = rows_steps<8>(a, sa, b, sb, acc); a += 32 * sa; b += 32 * sb; n -= 8; }
+  if (n >= 4) { acc = rows_steps<4>(a, sa, b, sb, acc); a += 16 * sa; b += 16 * sb; n -= 4; }
+  if (n >= 2) { acc = rows_steps<2>(a, sa, b, sb, acc); a += 8 * sa; b += 8 * sb; n -= 2; }
+  if (n >= 1) acc = rows_steps<1>(a, sa, b, sb, acc);
+  return acc;
 }
 
 // Three-source form (x2 != nullptr; the critic's batch of wgan.py:138-139,239-240 in ONE launch): images
@@ -234,14 +261,14 @@ __global__ __launch_bounds__(kRowsThreads) void blur_rows_kernel(const float* __
   extern __shared__ __attribute__((aligned(16))) float lds[];
   constexpr int NTH = kRowsThreads, NW = NTH / 64;
   const int Q = W * C, q4 = Q >> 2, half = T >> 1;
-  const int pitchY = Qp + 1, pitchZ = Qp + 4;
-  float* X = lds;                                             // [rows][Qp] source rows; later Z [32][pitchZ]
+  const int pitchX = rows_pitch(Qp, 16), pitchY = rows_pitch(Qp, 4), pitchZ = rows_pitch(Qp, 4);
+  float* X = lds;                                             // [rows][pitchX] source rows; later Z [32][pitchZ]
   float* Y = lds + xfloats;                                   // [32][pitchY] after the H pass
   float* tz = Y + ((kRowsBlock * pitchY + 3) & ~3);           // [kTzPad zeros][T taps][kTzPad zeros]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int img = blockIdx.x / nb, rb = blockIdx.x - img * nb, r0 = rb * kRowsBlock;
   const int ks = max(0, r0 - half), ke = min(H, r0 + kRowsBlock + half);       // source rows [ks, ke)
-  const int nk = ke - ks, nk2 = (nk + 1) & ~1;
+  const int nk = ke - ks, nk4 = (nk + 3) & ~3;
   const int grp = x2 ? img / Bs : 0, bimg = x2 ? img - grp * Bs : img;          // source group and image within it
   const float* xi = (grp == 1 ? x2 : x) + (size_t)bimg * H * Q;
   float* yi = y + (size_t)img * H * Q;
@@ -250,10 +277,9 @@ __global__ __launch_bounds__(kRowsThreads) void blur_rows_kernel(const float* __
   // odd k of the last MFMA pair (when the block needs an odd number of source rows)
   if (Qp != Q) {
     const int padc = Qp - Q;
-    for (int e = tid; e < nk * padc; e += NTH) X[(e / padc) * Qp + Q + e % padc] = 0.f;
+    for (int e = tid; e < nk * padc; e += NTH) X[(e / padc) * pitchX + Q + e % padc] = 0.f;
   }
-  if (nk2 != nk)
-    for (int e = tid; e < Qp; e += NTH) X[nk * Qp + e] = 0.f;
+  for (int e = tid; e < (nk4 - nk) * Qp; e += NTH) X[(nk + e / Qp) * pitchX + e % Qp] = 0.f;
   if (grp == 2) {                                              // x-hat rows: r + a * (f - r), r = x2, f = x (workgroup-uniform branch)
     const float4* sf = reinterpret_cast<const float4*>(xi + (size_t)ks * Q);
     const float4* sr = reinterpret_cast<const float4*>(x2 + (size_t)bimg * H * Q + (size_t)ks * Q);
@@ -264,47 +290,68 @@ __global__ __launch_bounds__(kRowsThreads) void blur_rows_kernel(const float* __
       const float4 f = sf[i], r = sr[i];
       float4 v;
       v.x = r.x + a * (f.x - r.x); v.y = r.y + a * (f.y - r.y); v.z = r.z + a * (f.z - r.z); v.w = r.w + a * (f.w - r.w);
-      *reinterpret_cast<float4*>(X + row * Qp + 4 * c4) = v;
+      *reinterpret_cast<float4*>(X + row * pitchX + 4 * c4) = v;
     }
   } else {
     const float4* src = reinterpret_cast<const float4*>(xi + (size_t)ks * Q);
     const int total4 = nk * q4;
     for (int i = tid; i < total4; i += NTH) {
       const int row = fdiv(i, dQ4), c4 = i - row * q4;
-      *reinterpret_cast<float4*>(X + row * Qp + 4 * c4) = src[i];
+#if defined(BG_DIAG) && defined(ROWS_NO_MEM)
+      *reinterpret_cast<float4*>(X + row * pitchX + 4 * c4) = float4{0.5f, 0.25f, (float)i, 1.f};
+      (void)src;
+#else
+      *reinterpret_cast<float4*>(X + row * pitchX + 4 * c4) = src[i];
+#endif
     }
   }
   __syncthreads();
-  const int li = lane & 31, kk = lane >> 5;
-  // ---- H pass: Y[m][q] = sum_k t[(ks + k) - (r0 + m) + half] * X[k][q];  A = Toeplitz, B = source rows, one 32-column tile per wave
-  for (int item = wave; item < Qp / 32; item += NW) {
-    floatx16 acc;
+  // Both passes on v_mfma_f32_16x16x4_f32 over 16 x 16 tiles restricted to the BAND (round 4).  The 32 x 32 x 2 form gave a
+  // workgroup 6 items per pass for its 8 waves (two SIMDs carried twice the chains of the other two) and contracted over all
+  // source rows / all 64 columns although a tile only sees taps within half a kernel of it: with every global load and store
+  // knocked out the kernel still took 11.5 of its 14.0 us at 256 x 64x64x3 / 31 taps -- the matrix pipe of the busiest SIMD was
+  // the floor, not memory and not the launch.  16-wide tiles: 24 items per pass (3 per wave), 12 k-steps of 4 instead of 24 + 32 of 2.
+  const int l16 = lane & 15, kq = lane >> 4;
+  const int rts = (min(kRowsBlock, H - r0) + 15) >> 4;            // 16-row tiles of this block that hold output rows
+  // ---- H pass: Y[m][q] = sum_k t[(ks + k) - (r0 + m) + half] * X[k][q];  A = Toeplitz [16 rows x 4 k], B = source rows [4 k x 16 columns]
+  {
+    const int nct = Qp >> 4;
+#if defined(BG_DIAG) && defined(ROWS_NO_H)
+    for (int item = wave; item < (int)(tz[0] != 0.f); item += NW) {
+#else
+    for (int item = wave; item < rts * nct; item += NW) {
+#endif
+      const int rt = item / nct, ct = item - rt * nct;
+      const int klo = max(0, r0 + 16 * rt - half - ks) & ~3, khi = min(nk4, (r0 + 16 * rt + 16 + half - ks + 3) & ~3);
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* ta = tz + kTzPad + half + ks - (r0 + 16 * rt + l16) + kq;      // + k
+      const float* xb = X + kq * pitchX + 16 * ct + l16;                            // + k * pitchX
+      acc = rows_chain(ta + klo, 1, xb + klo * pitchX, pitchX, (khi - klo) >> 2, acc);
+      float* yo = Y + (16 * rt + 4 * kq) * pitchY + 16 * ct + l16;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    const float* ta = tz + kTzPad + half + ks - r0 - li + kk;       // + k
-    const float* xb = X + kk * Qp + 32 * item + li;                 // + k * Qp
-#pragma unroll 8
-    for (int kp = 0; kp < nk2 / 2; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ta[2 * kp], xb[2 * kp * Qp], acc, 0, 0, 0);
-    float* yo = Y + (4 * kk) * pitchY + 32 * item + li;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) yo[((q & 3) + 8 * (q >> 2)) * pitchY] = acc[q];
+      for (int i = 0; i < 4; ++i) yo[i * pitchY] = acc[i];
+    }
   }
   __syncthreads();
   // ---- W pass per channel: Z[m][x, c] = sum_x' Y[m][x', c] * t[x' - x + half];  A = Y (lanes along rows), B = Toeplitz
   float* Z = X;                                                     // X is dead: every wave passed the barrier above
-  const int xts = Wp / 32;
-  for (int item = wave; item < C * xts; item += NW) {
-    const int c = item / xts, xt = item - c * xts;
-    floatx16 acc;
+  {
+    const int xts = Wp >> 4;
+#if defined(BG_DIAG) && defined(ROWS_NO_W)
+    for (int item = wave; item < (int)(tz[0] != 0.f); item += NW) {
+#else
+    for (int item = wave; item < rts * C * xts; item += NW) {
+#endif
+      const int rt = item / (C * xts), rem = item - rt * (C * xts), c = rem / xts, xt = rem - c * xts;
+      const int lo = max(0, 16 * xt - half) & ~3, hi = min(Wp, (16 * xt + 16 + half + 3) & ~3);
+      floatx4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* ya = Y + (16 * rt + l16) * pitchY + kq * C + c;  // + x' * C
+      const float* tb = tz + kTzPad + half - (16 * xt + l16) + kq;  // + x'
+      acc = rows_chain(ya + lo * C, C, tb + lo, 1, (hi - lo) >> 2, acc);
+      float* zo = Z + (16 * rt + 4 * kq) * pitchZ + (16 * xt + l16) * C + c;
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[q] = 0.f;
-    const float* ya = Y + li * pitchY + kk * C + c;                 // + k * C
-    const float* tb = tz + kTzPad + half - (32 * xt + li) + kk;     // + k
-#pragma unroll 8
-    for (int kp = 0; kp < Wp / 2; ++kp) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ya[2 * kp * C], tb[2 * kp], acc, 0, 0, 0);
-    float* zo = Z + (4 * kk) * pitchZ + (32 * xt + li) * C + c;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) zo[((q & 3) + 8 * (q >> 2)) * pitchZ] = acc[q];
+      for (int i = 0; i < 4; ++i) zo[i * pitchZ] = acc[i];
+    }
   }
   __syncthreads();
   {
@@ -312,7 +359,11 @@ __global__ __launch_bounds__(kRowsThreads) void blur_rows_kernel(const float* __
     const int total4 = min(kRowsBlock, H - r0) * q4;
     for (int i = tid; i < total4; i += NTH) {
       const int row = fdiv(i, dQ4), c4 = i - row * q4;
-      dst[i] = *reinterpret_cast<const float4*>(Z + row * pitchZ + 4 * c4);
+      const float4 zv = *reinterpret_cast<const float4*>(Z + row * pitchZ + 4 * c4);
+#if defined(BG_DIAG) && defined(ROWS_NO_MEM)
+      if (zv.x == 123.456f)                                    // never true: keeps the data flow, drops the store traffic
+#endif
+      dst[i] = zv;
     }
   }
 }
@@ -695,7 +746,6 @@ void launch_band_t(hipStream_t s, const float* src, float* dst, int B, int R, in
 // SAME zero padding is zeros in LDS (rows / columns outside the image load as 0), never a modified Toeplitz block.
 // The next chunk's global loads are issued into registers before the current chunk's MFMAs; two workgroups per CU.
 // ------------------------------------------------------------------------------------------------
-typedef float floatx4 __attribute__((ext_vector_type(4)));
 constexpr int kSP = 32;                                       // output pixel columns per strip
 
 // P = reach of the band on either side of a 16-wide output block, a multiple of 4 >= taps/2: the block contracts over
