@@ -58,14 +58,14 @@ SIGNATURES = {
     "bg_bn_train_fwd_partials": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _i, _f, _p]),
     "bg_bn_sums_from_partials": (_i, [_p, _i, _i, _p, _p]),
     "bg_bn_infer_fwd": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _f, _f, _p]),
-    "bg_bn_train_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _f, _p, _z, _p]),
+    "bg_bn_train_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _z, _p]),
     "bg_bn_fold_f32": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
     "bg_bn_stats_f32": (_i, [_p, _i, _i, _p, _p, _z, _p]),
     "bg_bn_finalize_f32": (_i, [_p, _i, _i, _p, _p, _p, _p, _f, _f, _i, _p]),
     "bg_bn_apply_f32": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _f, _p]),
     "bg_bn_finalize_apply_f32": (_i, [_p, _i, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _f, _i, _f, _p]),
-    "bg_bn_bwd_stats_f32": (_i, [_p, _p, _p, _i, _i, _p, _p, _f, _p, _p, _z, _p]),
-    "bg_bn_bwd_apply_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _f, _p]),
+    "bg_bn_bwd_stats_f32": (_i, [_p, _p, _p, _i, _i, _p, _p, _p, _p, _f, _p, _p, _z, _p]),
+    "bg_bn_bwd_apply_f32": (_i, [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p, _f, _p]),
     "bg_bn_param_grads_f32": (_i, [_p, _i, _f, _p, _p, _p]),
     "bg_lerp_f32": (_i, [_p, _p, _p, _p, _i, _i, _p]),
     "bg_row_norm_f32": (_i, [_p, _p, _i, _i, _p]),

@@ -246,13 +246,27 @@ __global__ __launch_bounds__(kT) void bn_stats_flat_kernel(const float* __restri
   }, M, C, partial);
 }
 
+// y == nullptr (all three backward kernels): the sign of the activation is re-derived from x with the forward's own expression
+// (bn_apply_kernel: v = gamma * ((x - mean) * inv) + beta, y = v > 0 ? v : alpha * v, so y > 0 <=> v > 0 for alpha >= 0 -- the same
+// operations on the same inputs, hence the same bits) and the saved activation is not read: one tensor less per pass.
+__device__ __forceinline__ float bn_pre_act(float x, float g, float m, float iv, float bt) { return g * ((x - m) * iv) + bt; }
+
 __global__ __launch_bounds__(kT) void bn_bwd_flat_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                         const float* __restrict__ x, int M, int C, const float* __restrict__ mean,
+                                                         const float* __restrict__ x, int M, int C, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ mean,
                                                          const float* __restrict__ inv, float alpha, float* partial) {
   flat_reduce<2>([&](size_t q4, int c4, float4* a) {
-    const float4 d = reinterpret_cast<const float4*>(dy)[q4], yy = reinterpret_cast<const float4*>(y)[q4],
-                 xx = reinterpret_cast<const float4*>(x)[q4];
+    const float4 d = reinterpret_cast<const float4*>(dy)[q4], xx = reinterpret_cast<const float4*>(x)[q4];
     const float4 mu = *reinterpret_cast<const float4*>(mean + c4), iv = *reinterpret_cast<const float4*>(inv + c4);
+    float4 yy;
+    if (y) {
+      yy = reinterpret_cast<const float4*>(y)[q4];
+    } else {
+      const float4 g = make_float4(gamma[c4], gamma[c4 + 1], gamma[c4 + 2], gamma[c4 + 3]);
+      const float4 bt = make_float4(beta[c4], beta[c4 + 1], beta[c4 + 2], beta[c4 + 3]);
+      yy.x = bn_pre_act(xx.x, g.x, mu.x, iv.x, bt.x); yy.y = bn_pre_act(xx.y, g.y, mu.y, iv.y, bt.y);
+      yy.z = bn_pre_act(xx.z, g.z, mu.z, iv.z, bt.z); yy.w = bn_pre_act(xx.w, g.w, mu.w, iv.w, bt.w);
+    }
     const float dz0 = d.x * (yy.x > 0.f ? 1.f : alpha), dz1 = d.y * (yy.y > 0.f ? 1.f : alpha);
     const float dz2 = d.z * (yy.z > 0.f ? 1.f : alpha), dz3 = d.w * (yy.w > 0.f ? 1.f : alpha);
     a[0].x += dz0; a[0].y += dz1; a[0].z += dz2; a[0].w += dz3;
@@ -421,12 +435,14 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const float* __restrict__ 
 }
 
 __global__ __launch_bounds__(kT) void bn_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ y,
-                                                            const float* __restrict__ x, int M, int C,
+                                                            const float* __restrict__ x, int M, int C, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta,
                                                             const float* __restrict__ mean, const float* __restrict__ inv, float alpha,
                                                             float* partial) {
   col_reduce<2>([&](int m, int n, float* a) {
     const size_t e = (size_t)m * C + n;
-    const float dz = dy[e] * (y[e] > 0.f ? 1.f : alpha);
+    const float yv = y ? y[e] : bn_pre_act(x[e], gamma[n], mean[n], inv[n], beta[n]);
+    const float dz = dy[e] * (yv > 0.f ? 1.f : alpha);
     a[0] += dz;
     a[1] = fmaf(dz, (x[e] - mean[n]) * inv[n], a[1]);
   }, M, C, partial);
@@ -443,21 +459,30 @@ __global__ __launch_bounds__(kT) void bn_bwd_final_kernel(const float* __restric
 
 __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ y,
                                                           const float* __restrict__ x, float* __restrict__ dx, size_t total, int M /* rows behind the statistics */, int C,
-                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean,
                                                           const float* __restrict__ inv, const float* __restrict__ dgamma,
                                                           const float* __restrict__ dbeta, float alpha) {
   const float invM = 1.0f / (float)M;
   if ((C & 3) == 0 && ptr_al16(dy) && ptr_al16(y) && ptr_al16(x) && ptr_al16(dx) && total <= 0xffffffffull) {     // see bn_apply_kernel
-    const bool pa = ptr_al16(gamma) && ptr_al16(mean) && ptr_al16(inv) && ptr_al16(dgamma) && ptr_al16(dbeta);
+    const bool pa = ptr_al16(gamma) && ptr_al16(mean) && ptr_al16(inv) && ptr_al16(dgamma) && ptr_al16(dbeta) && ptr_al16(beta);
     const unsigned total4 = (unsigned)(total >> 2);
     const float fM = (float)M;
     for (unsigned q = blockIdx.x * kT + threadIdx.x; q < total4; q += gridDim.x * kT) {
       const unsigned e = q * 4u;
       const int c = (int)(e % (unsigned)C);
-      const float4 dyv = *reinterpret_cast<const float4*>(dy + e), yv = *reinterpret_cast<const float4*>(y + e);
+      const float4 dyv = *reinterpret_cast<const float4*>(dy + e);
       const float4 xv = *reinterpret_cast<const float4*>(x + e);
       const float4 g = load4_param(gamma, c, pa), m = load4_param(mean, c, pa), iv = load4_param(inv, c, pa);
       const float4 dg = load4_param(dgamma, c, pa), db = load4_param(dbeta, c, pa);
+      float4 yv;
+      if (y) {
+        yv = *reinterpret_cast<const float4*>(y + e);
+      } else {
+        const float4 bt = load4_param(beta, c, pa);
+        yv.x = bn_pre_act(xv.x, g.x, m.x, iv.x, bt.x); yv.y = bn_pre_act(xv.y, g.y, m.y, iv.y, bt.y);
+        yv.z = bn_pre_act(xv.z, g.z, m.z, iv.z, bt.z); yv.w = bn_pre_act(xv.w, g.w, m.w, iv.w, bt.w);
+      }
       float4 o;
 #define BG_BN_BWD1(k)                                                   \
   {                                                                     \
@@ -473,7 +498,8 @@ __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(const float* __restric
   }
   for (size_t e = (size_t)blockIdx.x * kT + threadIdx.x; e < total; e += (size_t)gridDim.x * kT) {
     const int c = (int)(e % C);
-    const float dz = dy[e] * (y[e] > 0.f ? 1.f : alpha);
+    const float yv = y ? y[e] : bn_pre_act(x[e], gamma[c], mean[c], inv[c], beta[c]);
+    const float dz = dy[e] * (yv > 0.f ? 1.f : alpha);
     const float xh = (x[e] - mean[c]) * inv[c];
     dx[e] = gamma[c] * inv[c] * invM * ((float)M * dz - dbeta[c] - xh * dgamma[c]);
   }
@@ -700,15 +726,27 @@ __global__ __launch_bounds__(kT) void uniform_kernel(float* out, size_t n, uint6
   }
 }
 
+// element e takes word e % 4 of the Philox block with counter offset + e / 4 (the layout the oracle restates); a thread forms 16
+// consecutive elements (four blocks) and leaves them with ONE 16-byte store -- byte stores held this kernel at 1.3 TB/s
 __global__ __launch_bounds__(kT) void keep_mask_kernel(uint8_t* out, size_t n, float keep_prob, uint64_t seed, uint64_t offset) {
-  const size_t nq = (n + 3) / 4;
-  for (size_t q = (size_t)blockIdx.x * kT + threadIdx.x; q < nq; q += (size_t)gridDim.x * kT) {
-    const uint64_t ctr = offset + q;
-    uint32_t r[4];
-    philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+  const size_t n16 = (n + 15) / 16;
+  const bool al16 = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+  for (size_t t = (size_t)blockIdx.x * kT + threadIdx.x; t < n16; t += (size_t)gridDim.x * kT) {
+    uint32_t w[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
-      if (q * 4 + i < n) out[q * 4 + i] = u01(r[i]) < keep_prob ? 1 : 0;
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t ctr = offset + t * 4 + j;
+      uint32_t r[4];
+      philox4x32_10((uint32_t)ctr, (uint32_t)(ctr >> 32), 1u, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+      w[j] = (u01(r[0]) < keep_prob ? 1u : 0u) | (u01(r[1]) < keep_prob ? 0x100u : 0u) | (u01(r[2]) < keep_prob ? 0x10000u : 0u) |
+             (u01(r[3]) < keep_prob ? 0x1000000u : 0u);
+    }
+    if (al16 && t * 16 + 15 < n) {
+      *reinterpret_cast<uint4*>(out + t * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    } else {
+      for (int i = 0; i < 16; ++i)
+        if (t * 16 + i < n) out[t * 16 + i] = (uint8_t)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+    }
   }
 }
 
@@ -840,21 +878,22 @@ int bg_bn_infer_fwd(const float* x, float* y, int M, int C, const float* gamma, 
   return L.done("bn_apply_kernel");
 }
 
-int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, int M, int C, const float* gamma,
+int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, int M, int C, const float* gamma, const float* beta,
                     const float* save_mean, const float* save_inv, float* dgamma, float* dbeta, float lrelu_alpha, void* ws_d,
                     size_t ws_bytes, void* stream) {
-  BG_REQUIRE(dy && y && x && dx && gamma && save_mean && save_inv && dgamma && dbeta, BG_ERR_NULL, "bg_bn_train_bwd: null pointer");
+  BG_REQUIRE(dy && (y || beta) && x && dx && gamma && save_mean && save_inv && dgamma && dbeta, BG_ERR_NULL, "bg_bn_train_bwd: null pointer");
+  BG_REQUIRE(y || lrelu_alpha >= 0.f, BG_ERR_UNSUPPORTED, "bg_bn_train_bwd: the sign of y follows from x only for lrelu_alpha >= 0");
   BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_train_bwd: M=%d C=%d", M, C);
   BG_REQUIRE(ws_d && ws_bytes >= bg_bn_workspace_bytes(M, C), BG_ERR_WORKSPACE, "bg_bn_train_bwd: workspace too small");
   const int nblk = red_blocks(M, C);
   float* partial = static_cast<float*>(ws_d);
   const size_t total = (size_t)M * C;
   {
-    bg::Launch L(stream, "bn_bwd_partial", 0, 12.0 * total);
+    bg::Launch L(stream, "bn_bwd_partial", 0, (y ? 12.0 : 8.0) * total);
     if (flat_ok(M, C) && bg::aligned16(dy) && bg::aligned16(y) && bg::aligned16(x) && bg::aligned16(save_mean) && bg::aligned16(save_inv))
-      bg::launch(bn_bwd_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv, lrelu_alpha, partial);
+      bg::launch(bn_bwd_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, dy, y, x, M, C, gamma, beta, save_mean, save_inv, lrelu_alpha, partial);
     else
-      bg::launch(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv,
+      bg::launch(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, gamma, beta, save_mean, save_inv,
                          lrelu_alpha, partial);
     int rc = L.done("bn_bwd_partial_kernel");
     if (rc) return rc;
@@ -865,8 +904,8 @@ int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, 
     int rc = L.done("bn_bwd_final_kernel");
     if (rc) return rc;
   }
-  bg::Launch L(stream, "bn_bwd_apply", 0, 16.0 * total);
-  bg::launch(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M, C, gamma, save_mean, save_inv,
+  bg::Launch L(stream, "bn_bwd_apply", 0, (y ? 16.0 : 12.0) * total);
+  bg::launch(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M, C, gamma, beta, save_mean, save_inv,
                      dgamma, dbeta, lrelu_alpha);
   return L.done("bn_bwd_apply_kernel");
 }
@@ -933,19 +972,21 @@ int bg_bn_finalize_apply_f32(const float* sums_d, int M_total, const float* x, f
   return L.done("bn_finalize_apply_kernel");
 }
 
-int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, int C, const float* save_mean,
-                        const float* save_inv, float lrelu_alpha, float* sums_d, void* ws_d, size_t ws_bytes, void* stream) {
-  BG_REQUIRE(dy && y && x && save_mean && save_inv && sums_d, BG_ERR_NULL, "bg_bn_bwd_stats_f32: null pointer");
+int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, int C, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_inv, float lrelu_alpha, float* sums_d, void* ws_d, size_t ws_bytes,
+                        void* stream) {
+  BG_REQUIRE(dy && (y || (gamma && beta)) && x && save_mean && save_inv && sums_d, BG_ERR_NULL, "bg_bn_bwd_stats_f32: null pointer");
+  BG_REQUIRE(y || lrelu_alpha >= 0.f, BG_ERR_UNSUPPORTED, "bg_bn_bwd_stats_f32: the sign of y follows from x only for lrelu_alpha >= 0");
   BG_REQUIRE(M > 0 && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_bwd_stats_f32: M=%d C=%d", M, C);
   BG_REQUIRE(ws_d && ws_bytes >= bg_bn_workspace_bytes(M, C), BG_ERR_WORKSPACE, "bg_bn_bwd_stats_f32: workspace too small");
   const int nblk = red_blocks(M, C);
   float* partial = static_cast<float*>(ws_d);
   {
-    bg::Launch L(stream, "bn_bwd_partial", 0, 12.0 * M * C);
+    bg::Launch L(stream, "bn_bwd_partial", 0, (y ? 12.0 : 8.0) * M * C);
     if (flat_ok(M, C) && bg::aligned16(dy) && bg::aligned16(y) && bg::aligned16(x) && bg::aligned16(save_mean) && bg::aligned16(save_inv))
-      bg::launch(bn_bwd_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv, lrelu_alpha, partial);
+      bg::launch(bn_bwd_flat_kernel, dim3(nblk), dim3(kT), 0, L.s, dy, y, x, M, C, gamma, beta, save_mean, save_inv, lrelu_alpha, partial);
     else
-      bg::launch(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, save_mean, save_inv,
+      bg::launch(bn_bwd_partial_kernel, dim3(nblk, bg::cdiv(C, 64)), dim3(kT), 0, L.s, dy, y, x, M, C, gamma, beta, save_mean, save_inv,
                          lrelu_alpha, partial);
     int rc = L.done("bn_bwd_partial_kernel");
     if (rc) return rc;
@@ -956,12 +997,14 @@ int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, 
 }
 
 int bg_bn_bwd_apply_f32(const float* dy, const float* y, const float* x, float* dx, int M, int M_total, int C, const float* gamma,
-                        const float* save_mean, const float* save_inv, const float* sums_d, float lrelu_alpha, void* stream) {
-  BG_REQUIRE(dy && y && x && dx && gamma && save_mean && save_inv && sums_d, BG_ERR_NULL, "bg_bn_bwd_apply_f32: null pointer");
+                        const float* beta, const float* save_mean, const float* save_inv, const float* sums_d, float lrelu_alpha,
+                        void* stream) {
+  BG_REQUIRE(dy && (y || beta) && x && dx && gamma && save_mean && save_inv && sums_d, BG_ERR_NULL, "bg_bn_bwd_apply_f32: null pointer");
+  BG_REQUIRE(y || lrelu_alpha >= 0.f, BG_ERR_UNSUPPORTED, "bg_bn_bwd_apply_f32: the sign of y follows from x only for lrelu_alpha >= 0");
   BG_REQUIRE(M > 0 && M_total >= M && C > 0, BG_ERR_BAD_SHAPE, "bg_bn_bwd_apply_f32: M=%d M_total=%d C=%d", M, M_total, C);
   const size_t total = (size_t)M * C;
-  bg::Launch L(stream, "bn_bwd_apply", 0, 16.0 * total);
-  bg::launch(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M_total, C, gamma, save_mean, save_inv,
+  bg::Launch L(stream, "bn_bwd_apply", 0, (y ? 16.0 : 12.0) * total);
+  bg::launch(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(kT), 0, L.s, dy, y, x, dx, total, M_total, C, gamma, beta, save_mean, save_inv,
                      sums_d + C /* dgamma = sum dz*xhat */, sums_d /* dbeta = sum dz */, lrelu_alpha);
   return L.done("bn_bwd_apply_kernel");
 }
@@ -1099,7 +1142,7 @@ int bg_keep_mask_u8(uint8_t* out, size_t n, float keep_prob, uint64_t seed, uint
   BG_REQUIRE(keep_prob > 0.f && keep_prob <= 1.f, BG_ERR_BAD_SHAPE, "bg_keep_mask_u8: keep_prob=%g", keep_prob);
   bg::Launch L(stream, "rng_keep_mask", 0, 1.0 * n);
   const int slot = bg::take_bind(BG_BIND_RNG_OFFSET);
-  bg::launch(keep_mask_kernel, dim3(grid_for(n, 4)), dim3(kT), 0, L.s, out, n, keep_prob, seed, offset);
+  bg::launch(keep_mask_kernel, dim3(grid_for(n, 16)), dim3(kT), 0, L.s, out, n, keep_prob, seed, offset);
   bg::bind_last(4, bg::BIND_U64, slot);
   return L.done("keep_mask_kernel");
 }

@@ -176,6 +176,7 @@ class Net:
         # statistics in the producing conv's epilogue: opt-in since round 3 -- the plain gather-GEMM variant now stores float4
         # (transposed accumulators), the statistics variant cannot, and the separate statistics pass costs less than that (C2
         # +0.24 %, C4 +0.3 % in a same-box A/B); BGAN_FUSED_BN_STATS=1 selects the fused form
+        self.bn_bwd_read_y = os.environ.get("BGAN_BN_BWD_READ_Y") == "1"
         self.fuse_bn_stats = os.environ.get("BGAN_FUSED_BN_STATS") == "1" and not os.environ.get("BGAN_NO_FUSED_BN_STATS")
 
     # ------------------------------------------------------------------ resources
@@ -403,6 +404,11 @@ class Net:
         x = x.to(self.device, torch.float32).contiguous()
         return self.forward(ctx, x, training=training, seed=np.random.randint(1 << 30)).clone()
 
+    def _bn_y(self, ctx, i):
+        """The saved activation the BatchNorm backward passes read for the LeakyReLU sign -- None by default: the kernels re-derive
+        the sign from z with the forward's own expression (bit-identical, one tensor less per pass).  BGAN_BN_BWD_READ_Y=1 reads it."""
+        return ctx.a[i] if self.bn_bwd_read_y else None
+
     # ------------------------------------------------------------------ backward
     def backward(self, ctx: Context, dout, need_dx=False, need_dw=True, beta=0.0, scale=1.0, reducer=None, dw_rows=None,
                  dx_rows=None, defer_conv_dw=False):
@@ -438,17 +444,18 @@ class Net:
                     world = dist.world_size()
                     sums = ctx.bn_sums(i, C)
                     if pending_stats is None:       # last stage: nothing above it to overlap with
-                        ops.bn_bwd_stats(gv, ctx.a[i], ctx.z[i], M, C, ctx.mean[i], ctx.inv[i], sums, ws, lrelu_alpha=st.alpha)
+                        ops.bn_bwd_stats(gv, self._bn_y(ctx, i), ctx.z[i], M, C, ctx.mean[i], ctx.inv[i], sums, ws, lrelu_alpha=st.alpha,
+                                         gamma=st.bn.vars["gamma"], beta=st.bn.vars["beta"])
                         pending_stats = dist.all_reduce_sum_async(sums)
                     pending_stats.wait()            # issued before the filter gradient of the stage above: it travelled meanwhile
                     pending_stats = None
-                    ops.bn_bwd_apply(gv, ctx.a[i], ctx.z[i], dz, M, M * world, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], sums,
-                                     lrelu_alpha=st.alpha)
+                    ops.bn_bwd_apply(gv, self._bn_y(ctx, i), ctx.z[i], dz, M, M * world, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], sums,
+                                     lrelu_alpha=st.alpha, beta=st.bn.vars["beta"])
                     if need_dw:     # the sums are already global: pre-divide so the flat gradient SUM all-reduce restores them
                         ops.bn_param_grads(sums, C, 1.0 / world, dg, db)
                 else:
-                    ops.bn_train_bwd(gv, ctx.a[i], ctx.z[i], dz, M, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], dg, db, ws,
-                                     lrelu_alpha=st.alpha)
+                    ops.bn_train_bwd(gv, self._bn_y(ctx, i), ctx.z[i], dz, M, C, st.bn.vars["gamma"], ctx.mean[i], ctx.inv[i], dg, db, ws,
+                                     lrelu_alpha=st.alpha, beta=st.bn.vars["beta"])
             elif st.act == "lrelu":
                 if g_is_dz:
                     dz = gv
@@ -551,8 +558,9 @@ class Net:
                 gp = tgt.view(B, *prev.out_shape)
                 Mp = gp.numel() // Cp
                 sums = ctx.bn_sums(i - 1, Cp)
-                ops.bn_bwd_stats(gp, ctx.a[i - 1], ctx.z[i - 1], Mp, Cp, ctx.mean[i - 1], ctx.inv[i - 1], sums,
-                                 self.workspace(ops._lib.load().bg_bn_workspace_bytes(Mp, Cp)), lrelu_alpha=prev.alpha)
+                ops.bn_bwd_stats(gp, self._bn_y(ctx, i - 1), ctx.z[i - 1], Mp, Cp, ctx.mean[i - 1], ctx.inv[i - 1], sums,
+                                 self.workspace(ops._lib.load().bg_bn_workspace_bytes(Mp, Cp)), lrelu_alpha=prev.alpha,
+                                 gamma=prev.bn.vars["gamma"], beta=prev.bn.vars["beta"])
                 pending_stats = dist.all_reduce_sum_async(sums)
                 if reducer is not None:             # slices finished before this exchange was issued may go out behind it now
                     for rng in deferred_ready:

@@ -246,10 +246,12 @@ def bn_infer_fwd(x, y, M, Cc, gamma, beta, moving_mean, moving_var, eps=1e-3, lr
     return y
 
 
-def bn_train_bwd(dy, y, x, dx, M, Cc, gamma, save_mean, save_inv, dgamma, dbeta, ws, lrelu_alpha=LRELU_ALPHA):
-    _f32(dy, y, x, dx)
+def bn_train_bwd(dy, y, x, dx, M, Cc, gamma, save_mean, save_inv, dgamma, dbeta, ws, lrelu_alpha=LRELU_ALPHA, beta=None):
+    """``y`` may be None when ``beta`` is given: the activation's sign is re-derived from ``x`` (bit-identical, one tensor less per
+    pass; include/bgan.h at bg_bn_train_bwd).  The same holds for bn_bwd_stats / bn_bwd_apply."""
+    _f32(dy, x, dx) if y is None else _f32(dy, y, x, dx)
     assert dy.numel() == M * Cc == dx.numel()
-    check(_lib.load().bg_bn_train_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(dx), M, Cc, _ptr(gamma), _ptr(save_mean), _ptr(save_inv),
+    check(_lib.load().bg_bn_train_bwd(_ptr(dy), _ptr(y), _ptr(x), _ptr(dx), M, Cc, _ptr(gamma), _ptr(beta), _ptr(save_mean), _ptr(save_inv),
                                       _ptr(dgamma), _ptr(dbeta), lrelu_alpha, _ptr(ws), ws.numel() * ws.element_size(),
                                       _stream()), "bg_bn_train_bwd")
     return dx
@@ -284,14 +286,14 @@ def bn_finalize_apply(sums, M_total, x, y, M, Cc, gamma, beta, save_mean, save_i
     return y
 
 
-def bn_bwd_stats(dy, y, x, M, Cc, save_mean, save_inv, sums, ws, lrelu_alpha=LRELU_ALPHA):
-    check(_lib.load().bg_bn_bwd_stats_f32(_ptr(dy), _ptr(y), _ptr(x), M, Cc, _ptr(save_mean), _ptr(save_inv), lrelu_alpha, _ptr(sums),
+def bn_bwd_stats(dy, y, x, M, Cc, save_mean, save_inv, sums, ws, lrelu_alpha=LRELU_ALPHA, gamma=None, beta=None):
+    check(_lib.load().bg_bn_bwd_stats_f32(_ptr(dy), _ptr(y), _ptr(x), M, Cc, _ptr(gamma), _ptr(beta), _ptr(save_mean), _ptr(save_inv), lrelu_alpha, _ptr(sums),
                                           _ptr(ws), ws.numel() * ws.element_size(), _stream()), "bg_bn_bwd_stats_f32")
     return sums
 
 
-def bn_bwd_apply(dy, y, x, dx, M, M_total, Cc, gamma, save_mean, save_inv, sums, lrelu_alpha=LRELU_ALPHA):
-    check(_lib.load().bg_bn_bwd_apply_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(dx), M, M_total, Cc, _ptr(gamma), _ptr(save_mean),
+def bn_bwd_apply(dy, y, x, dx, M, M_total, Cc, gamma, save_mean, save_inv, sums, lrelu_alpha=LRELU_ALPHA, beta=None):
+    check(_lib.load().bg_bn_bwd_apply_f32(_ptr(dy), _ptr(y), _ptr(x), _ptr(dx), M, M_total, Cc, _ptr(gamma), _ptr(beta), _ptr(save_mean),
                                           _ptr(save_inv), _ptr(sums), lrelu_alpha, _stream()), "bg_bn_bwd_apply_f32")
     return dx
 

@@ -106,7 +106,8 @@ class WGAN:
     def __init__(self, generator: Sequential, discriminator: Sequential, hyperparams: "WGAN.HyperParameters",
                  config: TrainingConfig, *args, reproduce_vector_loss_quirk: bool = True, sync_metrics: bool = True,
                  sync_batchnorm: bool = True, merge_critic_passes: bool = True, gp_zero_norm_guard: bool = False,
-                 merge_gp_filter_gradients: bool = True, step_replay: bool = True, **kwargs):
+                 merge_gp_filter_gradients: bool = True, step_replay: bool = True, persistent_input: bool = False,
+                 **kwargs):
         self.hparams = hyperparams
         if dist.world_size() > 1 and int(hyperparams.global_batch_size) != int(hyperparams.batch_size) * dist.world_size():
             import warnings
@@ -160,6 +161,7 @@ class WGAN:
         self.step_replay = step_replay and program.enabled_by_env()
         self._programs = program.StepPrograms()
         self._reals_stage = None
+        self.persistent_input = bool(persistent_input)
         self._rng_seed = get_seed()
         self._rng_off = 0
         self._bufs = {}
@@ -260,6 +262,13 @@ class WGAN:
         return self.device.type == "cuda" and G.capture_branches is None and D.capture_branches is None
 
     def _stage_reals(self, reals):
+        """The batch a recorded program reads.  A program holds device addresses, so by default the batch goes through ONE
+        persistent staging buffer (a copy of the batch per step, 4-10 us).  ``persistent_input = True`` (constructor keyword or
+        attribute) is the caller's promise that its batches arrive in device buffers that stay allocated and are refilled in
+        place (a prefetcher with one or two device buffers): programs are then recorded on those buffers directly -- the address
+        is part of the program key -- and no copy is made."""
+        if self.persistent_input:
+            return reals
         st = self._reals_stage
         if st is None or st.shape != reals.shape:
             st = self._reals_stage = torch.empty_like(reals)
@@ -271,7 +280,7 @@ class WGAN:
         """Everything that shapes the launch list of a step or is baked into its kernel arguments."""
         G, D = self.generator.net(), self.discriminator.net()
         hp = tuple(sorted((k, v) for k, v in vars(self.hparams).items() if isinstance(v, (int, float, str, bool))))
-        return (kind, tuple(reals.shape), D.blur_n_taps(), G.store.tr_dirty, D.store.tr_dirty, self.merge_critic_passes,
+        return (kind, tuple(reals.shape), reals.data_ptr(), D.blur_n_taps(), G.store.tr_dirty, D.store.tr_dirty, self.merge_critic_passes,
                 self.merge_gp_filter_gradients, self.sync_batchnorm, self.gp_zero_norm_guard, self.reproduce_vector_loss_quirk,
                 self.sync_metrics, dist.collectives_active(), dist.world_size(), G.fuse_bn_stats, D.fuse_bn_stats, hp)
 

@@ -172,9 +172,12 @@ int bg_bn_train_fwd(const float* x, float* y, int M, int C, const float* gamma, 
 /* inference forward with moving stats (generator inside the D-step, wgan.py:135). */
 int bg_bn_infer_fwd(const float* x, float* y, int M, int C, const float* gamma, const float* beta,
                     const float* moving_mean, const float* moving_var, float eps, float lrelu_alpha, void* stream);
-/* backward through lrelu + training BN: dy is the gradient w.r.t. y (post-lrelu), y the saved output. */
+/* backward through lrelu + training BN: dy is the gradient w.r.t. y (post-lrelu), y the saved output.
+ * y may be NULL (here and in bg_bn_bwd_stats_f32 / bg_bn_bwd_apply_f32) when beta is given and lrelu_alpha >= 0: the sign of y is
+ * then re-derived from x with the forward's own expression gamma * ((x - mean) * inv) + beta -- the same operations on the same
+ * inputs, so the result is bit-identical -- and each pass reads one tensor less. */
 int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, int M, int C,
-                    const float* gamma, const float* save_mean, const float* save_inv,
+                    const float* gamma, const float* beta, const float* save_mean, const float* save_inv,
                     float* dgamma, float* dbeta, float lrelu_alpha, void* ws_d, size_t ws_bytes, void* stream);
 
 /* inference BatchNormalization as a per-channel affine: scale = gamma / sqrt(moving_var + eps), shift = beta - moving_mean * scale
@@ -202,10 +205,12 @@ int bg_bn_train_fwd_partials(const float* partial_d, int nrows, const float* x, 
                              float momentum, int unbiased, float lrelu_alpha, void* stream);
 /* sums[0:C] = column sums, sums[C:2C] = sums of squares out of the same partials (SyncBN: what gets all-reduced) */
 int bg_bn_sums_from_partials(const float* partial_d, int nrows, int C, float* sums_d, void* stream);
-int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, int C, const float* save_mean,
-                        const float* save_inv, float lrelu_alpha, float* sums_d, void* ws_d, size_t ws_bytes, void* stream);
+int bg_bn_bwd_stats_f32(const float* dy, const float* y, const float* x, int M, int C, const float* gamma, const float* beta,
+                        const float* save_mean, const float* save_inv, float lrelu_alpha, float* sums_d, void* ws_d, size_t ws_bytes,
+                        void* stream);
 int bg_bn_bwd_apply_f32(const float* dy, const float* y, const float* x, float* dx, int M, int M_total, int C, const float* gamma,
-                        const float* save_mean, const float* save_inv, const float* sums_d, float lrelu_alpha, void* stream);
+                        const float* beta, const float* save_mean, const float* save_inv, const float* sums_d, float lrelu_alpha,
+                        void* stream);
 /* dbeta[c] = scale * sums[c], dgamma[c] = scale * sums[C + c]: gamma / beta gradients out of the all-reduced backward sums
    (scale = 1 / replicas, so that the SUM all-reduce of the flat gradient buffer restores the global value) */
 int bg_bn_param_grads_f32(const float* sums_d, int C, float scale, float* dgamma, float* dbeta, void* stream);

@@ -140,6 +140,36 @@ def test_rng_statistics_and_determinism():
     assert set(np.unique(k)) <= {0, 1} and abs(k.mean() - 0.7) < 2e-3
 
 
+def _philox4x32_10(ctr, key, c2):
+    """Philox4x32-10 (Salmon et al., SC'11) on arrays of 64-bit counters: counter words (lo, hi, c2, 0), key (lo, hi)."""
+    c = [(ctr & 0xFFFFFFFF).astype(np.uint64), (ctr >> np.uint64(32)).astype(np.uint64), np.full_like(ctr, c2), np.zeros_like(ctr)]
+    k0, k1 = np.uint64(key & 0xFFFFFFFF), np.uint64(key >> 32)
+    M0, M1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        c = [(p1 >> np.uint64(32)) ^ c[1] ^ k0, p1 & mask, (p0 >> np.uint64(32)) ^ c[3] ^ k1, p0 & mask]
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & mask, (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack(c, axis=1)
+
+
+@pytest.mark.parametrize("n,shift", [(4096, 0), (1000, 0), (1003, 1), (37, 5), (16 * 700 + 9, 16)])
+def test_rng_streams_are_counter_addressed(n, shift):
+    """The layout the step programs and the data-parallel offsets rely on: element e of a draw is word e % 4 of the Philox block
+    with counter offset + e / 4 (third counter word 0 for uniforms, 1 for keep masks), whatever the output's alignment and
+    however many elements a thread forms."""
+    from blurred_gan_amd import ops
+    seed, offset = 0x1234567, 77
+    blocks = _philox4x32_10(np.arange(offset, offset + (n + 3) // 4, dtype=np.uint64), seed, 1).reshape(-1)[:n]
+    u = (blocks >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0)
+    buf = torch.zeros(n + shift + 16, dtype=torch.uint8, device="cuda")
+    k = ops.keep_mask(buf[shift:shift + n], 0.7, seed, offset).cpu().numpy()
+    assert np.array_equal(k, (u < np.float32(0.7)).astype(np.uint8))
+    assert buf[:shift].sum().item() == 0 and buf[shift + n:].sum().item() == 0          # nothing written outside
+    blocks0 = _philox4x32_10(np.arange(offset, offset + (n + 3) // 4, dtype=np.uint64), seed, 0).reshape(-1)[:n]
+    got = ops.uniform(torch.empty(n, device="cuda"), seed, offset).cpu().numpy()
+    assert np.array_equal(got, (blocks0 >> np.uint64(8)).astype(np.float32) * np.float32(1.0 / 16777216.0))
+
+
 @pytest.mark.parametrize("src_hw,dst_hw,C", [((218, 178), (128, 128), 3), ((28, 28), (28, 28), 1), ((16, 20), (40, 33), 3)])
 def test_input_pipeline_kernel(src_hw, dst_hw, C):
     """N4 (demo_celeba.py:22-35): uint8 -> normalise -> bilinear resize on the device vs the oracle."""
@@ -179,6 +209,39 @@ def test_separable_batchnorm_pieces_equal_fused():
     ops.bn_bwd_stats(dy, y1, x, M, C, m1, i1, sums, ws)
     ops.bn_bwd_apply(dy, y1, x, dx2, M, M, C, gamma, m1, i1, sums)
     assert torch.equal(dx1, dx2) and torch.equal(db, sums[:C]) and torch.equal(dg, sums[C:])
+
+
+@pytest.mark.parametrize("shape,alpha", [((32, 8, 8, 64), 0.2), ((16, 4, 4, 64), 0.0), ((5, 3, 3, 7), 0.2), ((64, 16, 16, 128), 0.0)])
+def test_batchnorm_backward_without_saved_activation(shape, alpha):
+    """y = NULL: the sign of the activation is re-derived from x with the forward's expression -- every output of the fused and
+    of the separable backward is bit-identical to the route that reads the saved y (float4 and scalar kernels, ReLU and LeakyReLU;
+    values sit ON zero too: beta = 0, x = mean exactly for a constant channel)."""
+    from blurred_gan_amd import ops
+    rng = np.random.default_rng(5)
+    C = shape[-1]
+    M = int(np.prod(shape)) // C
+    xn = rng.normal(size=shape) * 2 + 0.3
+    xn[..., 0] = 1.25                                  # a constant channel: (x - mean) == 0, v == beta
+    x, dy = dev(xn), dev(rng.normal(size=shape))
+    bn_ = 0.1 * rng.normal(size=C)
+    bn_[0] = 0.0
+    gamma, beta = dev(1 + 0.2 * rng.normal(size=C)), dev(bn_)
+    ws = torch.empty(ops._lib.load().bg_bn_workspace_bytes(M, C) // 4 + 4, device="cuda")
+    mm, mv = dev(np.zeros(C)), dev(np.ones(C))
+    y = torch.empty(shape, device="cuda")
+    m, iv = torch.empty(C, device="cuda"), torch.empty(C, device="cuda")
+    ops.bn_train_fwd(x, y, M, C, gamma, beta, mm, mv, m, iv, ws, lrelu_alpha=alpha)
+    outs = []
+    for yy in (y, None):
+        dx, dx2 = torch.empty(shape, device="cuda"), torch.empty(shape, device="cuda")
+        dg, db, sums = torch.empty(C, device="cuda"), torch.empty(C, device="cuda"), torch.empty(2 * C, device="cuda")
+        ops.bn_train_bwd(dy, yy, x, dx, M, C, gamma, m, iv, dg, db, ws, lrelu_alpha=alpha, beta=beta)
+        ops.bn_bwd_stats(dy, yy, x, M, C, m, iv, sums, ws, lrelu_alpha=alpha, gamma=gamma, beta=beta)
+        ops.bn_bwd_apply(dy, yy, x, dx2, M, M, C, gamma, m, iv, sums, lrelu_alpha=alpha, beta=beta)
+        outs.append((dx, dg, db, sums, dx2))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert torch.equal(outs[1][0], outs[1][4])
 
 
 def test_gp_seed_zero_norm_quirk_and_guard():

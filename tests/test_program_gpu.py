@@ -54,6 +54,24 @@ def test_replayed_steps_equal_eager_steps_bit_for_bit(tmp_path, arch, B, sigmas)
     assert recs and all(r.n_launches > 10 for r in recs)
 
 
+def test_persistent_input_buffers_are_recorded_directly(tmp_path):
+    """persistent_input=True: a loader that refills its own device buffers in place (two of them, alternating): the programs are
+    recorded on those buffers (one program per address, no staging buffer, no copy) and leave the eager path's state."""
+    arch, B = "mnist", 8
+    eager = _make(arch, B, 11, tmp_path, False, 1.0)
+    prog = _make(arch, B, 11, tmp_path, True, 1.0, persistent_input=True)
+    g = torch.Generator().manual_seed(4)
+    bufs = [torch.empty(B, 28, 28, 1, device="cuda") for _ in range(2)]
+    for i in range(10):
+        batch = (torch.rand(B, 28, 28, 1, generator=g) * 2 - 1).cuda()
+        bufs[i % 2].copy_(batch)
+        assert eager.train_on_batch(batch) == prog.train_on_batch(bufs[i % 2]), i
+        _same_state(eager, prog)
+    assert prog._reals_stage is None
+    st = prog._programs.stats                            # per address one eager and one recording step (D and G), one more eager
+    assert st["replayed"] >= 10 and st["recorded"] == 4, st   # D-step while the generator's transposed kernels were still dirty
+
+
 def test_eager_and_replayed_steps_can_be_mixed(tmp_path):
     """discriminator_step / generator_step called directly (eager) between replayed train_on_batch calls, generate_samples in
     between, d_steps_per_g_step = 2 (batches without a G-step: other dirty flags, another program)."""
