@@ -60,6 +60,7 @@ SIGNATURES = {
     "bg_bn_infer_fwd": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _f, _f, _p]),
     "bg_bn_train_bwd": (_i, [_p, _p, _p, _p, _i, _i, _p, _p, _p, _p, _p, _p, _f, _p, _z, _p]),
     "bg_bn_fold_f32": (_i, [_p, _p, _p, _p, _f, _i, _p, _p, _p]),
+    "bg_bn_fold_many_f32": (_i, [_i, _p, _p, _p, _p, _p, _p, _p, _p, _p]),
     "bg_bn_stats_f32": (_i, [_p, _i, _i, _p, _p, _z, _p]),
     "bg_bn_finalize_f32": (_i, [_p, _i, _i, _p, _p, _p, _p, _f, _f, _i, _p]),
     "bg_bn_apply_f32": (_i, [_p, _p, _i, _i, _p, _p, _p, _p, _f, _p]),

@@ -276,9 +276,21 @@ __global__ __launch_bounds__(kT) void bn_bwd_flat_kernel(const float* __restrict
 }
 
 // one wave per channel sums the per-block partials: partial[(b*NQ + q)*C + c]
+// (the loads of a lane are issued eight at a time and added in the loop's own order: the sum keeps its bits, and a lane waits for
+// memory once per eight partial rows instead of once per row -- these finals are pure latency, 4-7 us for microseconds of work)
 __device__ inline float wave_sum_partials(const float* __restrict__ partial, int nblk, int NQ, int q, int C, int c) {
   float s = 0.f;
-  for (int b = threadIdx.x & 63; b < nblk; b += 64) s += partial[((size_t)b * NQ + q) * C + c];
+  int b = threadIdx.x & 63;
+  const size_t step = (size_t)64 * NQ * C;
+  const float* p = partial + ((size_t)b * NQ + q) * C + c;
+  for (; b + 7 * 64 < nblk; b += 8 * 64, p += 8 * step) {
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = p[i * step];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+  }
+  for (; b < nblk; b += 64, p += step) s += *p;
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   return __shfl(s, 0, 64);
 }
@@ -336,6 +348,22 @@ __global__ __launch_bounds__(kT) void bn_fold_kernel(const float* __restrict__ g
   const float s = gamma[c] * (1.0f / sqrtf(mv[c] + eps));
   scale[c] = s;
   shift[c] = beta[c] - mm[c] * s;
+}
+
+// bn_fold_kernel for up to kFoldMax layers in ONE launch (blockIdx.y = layer): the generator's inference forward inside the D-step
+// folds every BatchNorm before its first conv instead of one tiny launch between each pair of convs
+constexpr int kFoldMax = 8;
+struct FoldMany {
+  const float* gamma[kFoldMax]; const float* beta[kFoldMax]; const float* mm[kFoldMax]; const float* mv[kFoldMax];
+  float* scale[kFoldMax]; float* shift[kFoldMax];
+  float eps[kFoldMax]; int C[kFoldMax];
+};
+__global__ __launch_bounds__(kT) void bn_fold_many_kernel(const FoldMany f) {
+  const int l = blockIdx.y, c = blockIdx.x * kT + threadIdx.x;
+  if (c >= f.C[l]) return;
+  const float s = f.gamma[l][c] * (1.0f / sqrtf(f.mv[l][c] + f.eps[l]));
+  f.scale[l][c] = s;
+  f.shift[l][c] = f.beta[l][c] - f.mm[l][c] * s;
 }
 
 // sums[q*C + c] = sum over blocks of partial[(b*2 + q)*C + c]   (one wave per channel)
@@ -917,6 +945,26 @@ int bg_bn_fold_f32(const float* gamma, const float* beta, const float* moving_me
   bg::Launch L(stream, "bn_fold", 0, 0);
   bg::launch(bn_fold_kernel, dim3(bg::cdiv(C, kT)), dim3(kT), 0, L.s, gamma, beta, moving_mean, moving_var, eps, C, scale_out, shift_out);
   return L.done("bn_fold_kernel");
+}
+
+int bg_bn_fold_many_f32(int n, const float* const* gamma, const float* const* beta, const float* const* moving_mean,
+                        const float* const* moving_var, const float* eps, const int* C, float* const* scale_out, float* const* shift_out,
+                        void* stream) {
+  BG_REQUIRE(gamma && beta && moving_mean && moving_var && eps && C && scale_out && shift_out, BG_ERR_NULL, "bg_bn_fold_many_f32: null pointer");
+  BG_REQUIRE(n > 0 && n <= kFoldMax, BG_ERR_BAD_SHAPE, "bg_bn_fold_many_f32: n=%d (1..%d)", n, kFoldMax);
+  FoldMany f{};
+  int cmax = 0;
+  for (int l = 0; l < n; ++l) {
+    BG_REQUIRE(gamma[l] && beta[l] && moving_mean[l] && moving_var[l] && scale_out[l] && shift_out[l], BG_ERR_NULL,
+               "bg_bn_fold_many_f32: null pointer in layer %d", l);
+    BG_REQUIRE(C[l] > 0, BG_ERR_BAD_SHAPE, "bg_bn_fold_many_f32: C[%d]=%d", l, C[l]);
+    f.gamma[l] = gamma[l]; f.beta[l] = beta[l]; f.mm[l] = moving_mean[l]; f.mv[l] = moving_var[l];
+    f.scale[l] = scale_out[l]; f.shift[l] = shift_out[l]; f.eps[l] = eps[l]; f.C[l] = C[l];
+    cmax = std::max(cmax, C[l]);
+  }
+  bg::Launch L(stream, "bn_fold", 0, 0);
+  bg::launch(bn_fold_many_kernel, dim3(bg::cdiv(cmax, kT), n), dim3(kT), 0, L.s, f);
+  return L.done("bn_fold_many_kernel");
 }
 
 static int bn_partials(const char* fn, const float* x, int M, int C, float* partial, void* stream) {

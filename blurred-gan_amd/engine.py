@@ -306,6 +306,21 @@ class Net:
         if training and masks is None and ctx.keep_rate is not None and ctx.keep_total:
             ops.keep_mask(ctx.keep_flat[:ctx.keep_total], 1.0 - ctx.keep_rate, seed, counter=(self, "rng_offset"))
             drawn = True
+        folded = ()
+        if not training:
+            # inference BatchNorms (the generator inside the D-step): every layer's fold in ONE launch ahead of the first conv
+            # instead of a tiny launch between each pair of convs (two kernel boundaries where one would do)
+            fl = [(j, s2) for j, s2 in enumerate(self.stages)
+                  if s2.bn is not None and s2.kind != "dense" and s2.lin.vars.get("bias") is None]
+            if 1 < len(fl) <= ops.FOLD_MAX and not os.environ.get("BGAN_NO_FOLD_MANY"):
+                args = []
+                for j, s2 in fl:
+                    Cj = s2.out_shape[-1]
+                    sc = ctx.bn_sums(j, Cj)
+                    v = s2.bn.vars
+                    args.append((v["gamma"], v["beta"], v["moving_mean"], v["moving_variance"], s2.bn.epsilon, sc[:Cj], sc[Cj:]))
+                ops.bn_fold_many(args)
+                folded = {j for j, _ in fl}
         for i, st in enumerate(self.stages):
             xin = x.view(B, *st.in_shape)
             ctx.xin[i] = xin
@@ -337,8 +352,9 @@ class Net:
                     C = st.out_shape[-1]
                     sc = ctx.bn_sums(i, C)
                     bn = st.bn
-                    ops.bn_fold(bn.vars["gamma"], bn.vars["beta"], bn.vars["moving_mean"], bn.vars["moving_variance"], bn.epsilon,
-                                sc[:C], sc[C:])
+                    if i not in folded:
+                        ops.bn_fold(bn.vars["gamma"], bn.vars["beta"], bn.vars["moving_mean"], bn.vars["moving_variance"], bn.epsilon,
+                                    sc[:C], sc[C:])
                     epi = self._epi(*geom, EPI_AFFINE_LRELU, bias=sc[C:], ref=sc[:C], alpha=st.alpha)
                     tgt = out
                 elif st.bn is not None:

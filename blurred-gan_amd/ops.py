@@ -262,6 +262,22 @@ def bn_fold(gamma, beta, moving_mean, moving_var, eps, scale_out, shift_out):
                                      _ptr(shift_out), _stream()), "bg_bn_fold_f32")
 
 
+FOLD_MAX = 8
+
+
+def bn_fold_many(layers):
+    """``layers``: up to FOLD_MAX tuples (gamma, beta, moving_mean, moving_var, eps, scale_out, shift_out) folded in ONE launch."""
+    import ctypes as C
+    n = len(layers)
+    assert 0 < n <= FOLD_MAX
+    P = C.c_void_p * n
+    cols = [P(*[_ptr(l[j]) for l in layers]) for j in (0, 1, 2, 3, 5, 6)]
+    eps = (C.c_float * n)(*[float(l[4]) for l in layers])
+    cs = (C.c_int * n)(*[int(l[0].numel()) for l in layers])
+    check(_lib.load().bg_bn_fold_many_f32(n, cols[0], cols[1], cols[2], cols[3], eps, cs, cols[4], cols[5], _stream()),
+          "bg_bn_fold_many_f32")
+
+
 def bn_stats(x, M, Cc, sums, ws):
     check(_lib.load().bg_bn_stats_f32(_ptr(x), M, Cc, _ptr(sums), _ptr(ws), ws.numel() * ws.element_size(), _stream()), "bg_bn_stats_f32")
     return sums

@@ -184,6 +184,11 @@ int bg_bn_train_bwd(const float* dy, const float* y, const float* x, float* dx, 
  * (feeds BG_EPI_AFFINE_LRELU so the generator's inference forward inside the D-step, wgan.py:135, needs no separate BN pass) */
 int bg_bn_fold_f32(const float* gamma, const float* beta, const float* moving_mean, const float* moving_var, float eps, int C,
                    float* scale_out, float* shift_out, void* stream);
+/* the same for n <= 8 layers in ONE launch (HOST arrays of n device pointers / values; same arithmetic per channel): every
+ * BatchNorm of the generator's inference forward is folded before its first conv */
+int bg_bn_fold_many_f32(int n, const float* const* gamma, const float* const* beta, const float* const* moving_mean,
+                        const float* const* moving_var, const float* eps, const int* C, float* const* scale_out,
+                        float* const* shift_out, void* stream);
 /* The same BatchNormalization in separable pieces, for data-parallel SyncBN: the per-channel sums are
  * all-reduced by the caller between the pieces.  sums_d = [2*C]: forward {sum x, sum x^2}; backward {sum dz, sum dz*xhat}
  * with dz = dy * lrelu'(y).  M_total = rows summed over all replicas. */

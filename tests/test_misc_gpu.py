@@ -244,6 +244,28 @@ def test_batchnorm_backward_without_saved_activation(shape, alpha):
     assert torch.equal(outs[1][0], outs[1][4])
 
 
+def test_bn_fold_many_equals_per_layer_folds():
+    """bg_bn_fold_many_f32: several layers' inference folds in one launch, bit-identical to one bg_bn_fold_f32 per layer (views into
+    a flat buffer at odd offsets, different channel counts and epsilons)."""
+    from blurred_gan_amd import ops
+    rng = np.random.default_rng(8)
+    Cs, eps = [512, 256, 64, 7, 300], [1e-3, 1e-3, 1e-5, 1e-3, 2e-3]
+    flat = dev(rng.normal(size=4 * sum(Cs) + 3))
+    layers, want, o = [], [], 1
+    for C, e in zip(Cs, eps):
+        g, b, mm, mv = (flat[o + k * C:o + (k + 1) * C] for k in range(4))
+        mv.abs_()
+        o += 4 * C
+        out = torch.zeros(2 * C, device="cuda")
+        ref = torch.zeros(2 * C, device="cuda")
+        ops.bn_fold(g, b, mm, mv, e, ref[:C], ref[C:])
+        layers.append((g, b, mm, mv, e, out[:C], out[C:]))
+        want.append((ref, out))
+    ops.bn_fold_many(layers)
+    for ref, out in want:
+        assert torch.equal(ref, out) and torch.isfinite(out).all()
+
+
 def test_gp_seed_zero_norm_quirk_and_guard():
     """A sample with an exactly-zero input gradient: the reference formula (n-1)/n * g is NaN there (as tf.norm's gradient at 0);
     the guarded entry point takes the subgradient 0 for that sample and leaves the others untouched."""
