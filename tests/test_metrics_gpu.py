@@ -61,3 +61,26 @@ def test_swd_and_fid_feeders_on_a_real_fit(tmp_path):
     for reals, _ in seen[:2]:
         same.update_state(reals, reals)
     assert same.results()["SWDx1e3_avg"] < want["SWDx1e3_avg"]
+
+
+def test_reference_golden_checks_on_the_gpu_box():
+    """The one upstream-pinned number of the repository (tests/golden/swd_golden.npz: outputs of the REFERENCE
+    sliced_wasserstein.py) re-checked where the product runs; tests/test_metrics_cpu.py is deselected by -m gpu."""
+    import test_metrics_cpu as cpu
+    cpu.test_pyramid_steps_match_reference()
+    cpu.test_descriptors_and_finalize_match_reference_with_same_seed()
+    cpu.test_sliced_wasserstein_matches_reference_with_same_seed()
+    cpu.test_api_end_to_end_matches_reference()
+
+
+def test_reference_api_result_with_batches_from_device_memory():
+    """The reference's API result on its golden batches, the batches travelling through device memory as generated samples do."""
+    import test_metrics_cpu as cpu
+    from blurred_gan_amd import sliced_wasserstein as sw
+    G = cpu.G
+    reals = torch.from_numpy(np.ascontiguousarray(G["api_reals"])).cuda()
+    fakes = torch.from_numpy(np.ascontiguousarray(G["api_fakes"])).cuda()
+    api = sw.API((4, 32, 32, 3), seed=2024)
+    api.begin("reals"); api.feed("reals", reals.cpu().numpy()); api.end("reals")
+    api.begin("fakes"); api.feed("fakes", fakes.cpu().numpy()); res = api.end("fakes")
+    np.testing.assert_allclose(res, G["api_result"], rtol=1e-4)
