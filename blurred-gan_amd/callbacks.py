@@ -33,27 +33,32 @@ class ExponentialDecay:
 
 
 class ExecuteEveryNExamplesCallback(Callback):
-    """callbacks.py:12-43."""
+    """A hook that fires once per ``n`` training EXAMPLES rather than per batch (reference callbacks.py:12-43).
+
+    Behaviour kept from the reference: examples are counted from the ``size`` entry of the batch logs; nothing fires before
+    ``starting_from`` examples have been seen (a negative value makes the first batch due at once); at most ONE call is made per
+    batch, so a batch that crosses several periods is caught up one batch at a time; the very first eligible batch fires
+    (period index 0).  Subclasses implement ``function(batch, logs)``."""
 
     def __init__(self, n: int, starting_from: int = 0):
         super().__init__()
-        self.period = n
-        self.num_invocations = 0
-        self.samples_seen = 0
-        self.starting_from = starting_from
+        self.period, self.starting_from = n, starting_from
+        self.samples_seen = 0          # examples counted so far
+        self.num_invocations = 0       # calls made so far == index of the next period that is owed a call
+
+    def periods_elapsed(self) -> int:
+        """Whole periods since ``starting_from`` (negative before it)."""
+        return (self.samples_seen - self.starting_from) // self.period
 
     def on_batch_end(self, batch, logs: Dict):
-        batch_size = logs["size"]
-        self.samples_seen += batch_size
-        i = (self.samples_seen - self.starting_from) // self.period
-        if self.samples_seen < self.starting_from:
-            return
-        if i >= self.num_invocations:
+        self.samples_seen += logs["size"]
+        owed = self.samples_seen >= self.starting_from and self.periods_elapsed() >= self.num_invocations
+        if owed:
             self.num_invocations += 1
             self.function(batch, logs)
 
     def function(self, batch, logs):
-        raise NotImplementedError("Implement the 'function' inside your class!")
+        raise NotImplementedError(f"{type(self).__name__} must implement function(batch, logs)")
 
 
 class BlurDecayController(Callback):
@@ -71,46 +76,53 @@ class BlurDecayController(Callback):
 
 
 class AdaptiveBlurController(Callback):
-    """callbacks.py:65-135 (the reference only *logs* "would_modify"; the assign is commented out at :102-103)."""
+    """Score-balance controller of the blur (reference callbacks.py:65-135).
+
+    It tracks an exponential moving average of fake / (real + fake) critic scores; once past ``warmup_n_batches`` it logs the raw
+    and smoothed ratio and whether the game counts as balanced (smoothed ratio within ``threshold`` of 0.5), and while balanced it
+    shrinks ITS OWN ``std`` by the smoothing factor, at most once per ``delay_between_modifications`` batches.  As in the reference
+    the shrunken value is only logged ("would_modify") -- the assignment to the model's blur is commented out there
+    (callbacks.py:102-103), so the model keeps the ``max_value`` set at train begin -- and training stops when the controller's
+    value falls under ``min_value``."""
+
+    delay_between_modifications = 100
+    _TAG = "blur_controller/"
 
     def __init__(self, smoothing=0.99, warmup_n_batches=100, threshold=0.05, min_value=0.01, max_value=23.5):
         super().__init__()
-        self.smoothing = smoothing
-        self.warmup_n_batches = warmup_n_batches
-        self.score_ratio = 0.5
-        self.threshold = threshold
-        self._last_modification_step = 0
-        self.delay_between_modifications = 100
+        self.smoothing, self.warmup_n_batches, self.threshold, self.min_value = smoothing, warmup_n_batches, threshold, min_value
         self.std = float(max_value)
-        self.min_value = min_value
+        self.score_ratio = 0.5                     # smoothed fake share of the scores; 0.5 = balanced
+        self._last_modification_step = 0
 
     def on_train_begin(self, logs=None):
         self.model.std.assign(self.std)
 
     def gan_problem_is_stable(self) -> bool:
-        return 0.5 - self.threshold <= self.score_ratio <= 0.5 + self.threshold
+        return abs(self.score_ratio - 0.5) <= self.threshold
+
+    def _scalars(self, **values):
+        with self.model.summary_writer.as_default() as w:
+            for name, v in values.items():
+                w.scalar(self._TAG + name, v)
 
     def decrease_blur_std(self, batch: int) -> None:
-        just_modified = batch - self._last_modification_step < self.delay_between_modifications
-        with self.model.summary_writer.as_default() as w:
-            if not just_modified:
-                self.std = self.smoothing * self.std
-                w.scalar("blur_controller/would_modify", 1)
-                self._last_modification_step = batch
-            else:
-                w.scalar("blur_controller/would_modify", 0)
+        """One multiplicative step, unless the previous one was fewer than ``delay_between_modifications`` batches ago."""
+        allowed = batch - self._last_modification_step >= self.delay_between_modifications
+        if allowed:
+            self.std *= self.smoothing
+            self._last_modification_step = batch
+        self._scalars(would_modify=int(allowed))
 
     def on_batch_end(self, batch, logs):
-        fake_scores, real_scores = logs["fake_scores"], logs["real_scores"]
-        ratio = fake_scores / (real_scores + fake_scores)
+        fake, real = logs["fake_scores"], logs["real_scores"]
+        ratio = fake / (real + fake)
         self.score_ratio = self.smoothing * self.score_ratio + (1 - self.smoothing) * ratio
         if batch < self.warmup_n_batches:
             return
-        with self.model.summary_writer.as_default() as w:
-            w.scalar("blur_controller/ratio", ratio)
-            w.scalar("blur_controller/smoothed_ratio", self.score_ratio)
-            w.scalar("blur_controller/stable", int(self.gan_problem_is_stable()))
-        if self.gan_problem_is_stable():
+        stable = self.gan_problem_is_stable()
+        self._scalars(ratio=ratio, smoothed_ratio=self.score_ratio, stable=int(stable))
+        if stable:
             self.decrease_blur_std(batch)
         if self.std < self.min_value:
             print("Reached the minimum STD. Training is complete.")

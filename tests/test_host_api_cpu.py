@@ -89,6 +89,61 @@ def test_execute_every_n_examples_counts():
     assert calls == [32, 128, 224, 320]
 
 
+def test_execute_every_n_examples_start_offset_and_catch_up():
+    """Nothing before ``starting_from``; a negative offset makes the first batch due; one call per batch while catching up."""
+    def run(n, start, sizes):
+        calls = []
+
+        class C(callbacks.ExecuteEveryNExamplesCallback):
+            def function(self, batch, logs):
+                calls.append((batch, self.samples_seen))
+        c = C(n=n, starting_from=start)
+        for b, sz in enumerate(sizes):
+            c.on_batch_end(b, {"size": sz})
+        return calls
+    assert run(100, 250, [64] * 8) == [(3, 256), (5, 384), (7, 512)]
+    assert run(16, -16, [8, 8, 8, 8]) == [(0, 8), (1, 16), (2, 24), (3, 32)]   # a head start of one period: a call every batch
+    assert run(10, 0, [35, 1, 1, 1, 1]) == [(0, 35), (1, 36), (2, 37), (3, 38)]
+    with pytest.raises(NotImplementedError):
+        callbacks.ExecuteEveryNExamplesCallback(5).on_batch_end(0, {"size": 8})
+
+
+def test_adaptive_blur_controller_logs_and_stops():
+    """callbacks.py:65-135: EMA of the fake share of the scores, silent during warm-up, one multiplicative step per 100 batches
+    while balanced (logged as would_modify, never assigned to the model), training stops under min_value."""
+    logged = []
+
+    class W:
+        def as_default(self):
+            import contextlib
+            return contextlib.nullcontext(self)
+
+        def scalar(self, name, value, step=None):
+            logged.append((name, value))
+
+    class M:
+        summary_writer, stop_training = W(), False
+    m = M()
+    m.std = bg.gaussian_blur.Variable(0.0)
+    ctl = callbacks.AdaptiveBlurController(smoothing=0.5, warmup_n_batches=3, threshold=0.05, min_value=1.0, max_value=4.0)
+    ctl.set_model(m)
+    ctl.on_train_begin()
+    assert float(m.std) == 4.0
+    for b in range(3):                                     # warm-up: the average moves, nothing is logged
+        ctl.on_batch_end(b, {"fake_scores": 1.0, "real_scores": 3.0})
+    assert not logged and abs(ctl.score_ratio - (0.25 + 0.25 * 0.5 ** 3)) < 1e-12 and not ctl.gan_problem_is_stable()
+    ctl.on_batch_end(3, {"fake_scores": 1.0, "real_scores": 3.0})
+    assert [n for n, _ in logged] == ["blur_controller/ratio", "blur_controller/smoothed_ratio", "blur_controller/stable"]
+    assert logged[-1][1] == 0 and ctl.std == 4.0
+    logged.clear()
+    ctl.score_ratio = 0.5
+    for b in (50, 120, 180, 230, 400):                     # balanced: steps at 120 (>= 100 after 0), 230, 400 -- not at 50 / 180
+        ctl.on_batch_end(b, {"fake_scores": 2.0, "real_scores": 2.0})
+    mods = [v for n, v in logged if n.endswith("would_modify")]
+    assert mods == [0, 1, 0, 1, 1] and ctl.std == 4.0 * 0.5 ** 3 and float(m.std) == 4.0
+    assert m.stop_training                                 # 0.5 < min_value
+
+
 def test_unsupported_layer_patterns_raise():
     s = layers.Sequential([layers.Dense(4, input_shape=(3,)), layers.LeakyReLU()])
     with pytest.raises(NotImplementedError):
