@@ -1532,7 +1532,13 @@ int bg_blur_nhwc_f32(const float* x, float* y, int B, int H, int W, int C, const
 
 int bg_blur3_lerp_supported(int B, int H, int W, int C, int n_taps) {
   if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || n_taps < 1 || !(n_taps & 1)) return 0;
-  return blur_path(3 * B, H, W, C, n_taps) == 5 ? 1 : 0;
+  if (blur_path(3 * B, H, W, C, n_taps) == 5) return 1;
+  // Below the tap count from which the row-block kernel is the single-source choice (13) the three-source launch still wins:
+  // at 28x28x1 / 3-7 taps every blur launch costs its ~5 us floor, and one launch replaces lerp + three of them (MNIST step)
+  return !getenv("BG_BLUR_NO_ROWS") && H <= 64 && W <= 64 && C <= 4 && ((W * C) & 3) == 0 && n_taps >= 3 &&
+                 rows_geom(H, W, C, n_taps).lds <= 80 * 1024
+             ? 1
+             : 0;
 }
 
 int bg_blur3_lerp_nhwc_f32(const float* f, const float* r, const float* alpha_b, float* y3, int B, int H, int W, int C, const float* taps_d,

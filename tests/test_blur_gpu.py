@@ -180,10 +180,13 @@ def test_blur_rejects_bad_arguments():
         ops.blur_nhwc(x, torch.empty_like(x), taps, 4)          # even tap count
 
 
-@pytest.mark.parametrize("B,H,W,C,sigma", [(5, 64, 64, 3, 5.0), (3, 32, 32, 3, 3.0), (4, 28, 28, 4, 2.5), (2, 64, 48, 1, 4.0), (7, 40, 64, 3, 10.5)])
+@pytest.mark.parametrize("B,H,W,C,sigma", [(5, 64, 64, 3, 5.0), (3, 32, 32, 3, 3.0), (4, 28, 28, 4, 2.5), (2, 64, 48, 1, 4.0), (7, 40, 64, 3, 10.5),
+                                           (6, 28, 28, 1, 0.05), (6, 28, 28, 1, 1.0), (3, 8, 8, 3, 0.9), (2, 64, 64, 3, 1.6)])
 def test_three_source_blur_with_the_lerp_formed_on_the_fly(B, H, W, C, sigma):
     """bg_blur3_lerp_nhwc_f32 (wgan.py:138-139, 239-240 in one launch): [blur(f); blur(r); blur(r + a (f - r))] must be BIT-identical
-    to bg_lerp_f32 followed by three bg_blur_nhwc_f32 calls -- x-hat is formed with the same expression while its rows are staged."""
+    to bg_lerp_f32 followed by three bg_blur_nhwc_f32 calls -- x-hat is formed with the same expression while its rows are staged.
+    Under 13 taps (the MNIST schedule: 3 taps at sigma 0.05) the single-source call runs the sliding-window kernel, whose sum order
+    differs from the Toeplitz product's: there the comparison is to rounding, and against the float64 oracle."""
     from blurred_gan_amd import ops
     g = torch.Generator(device="cuda").manual_seed(B * 100 + H)
     f = torch.rand(B, H, W, C, device="cuda", generator=g) * 2 - 1
@@ -198,12 +201,17 @@ def test_three_source_blur_with_the_lerp_formed_on_the_fly(B, H, W, C, sigma):
     tmp = torch.empty(nb // 4 + 4, device="cuda") if nb else None
     for i, src in enumerate((f, r, xhat)):
         want = ops.blur_nhwc(src, torch.empty_like(f), taps, nt, tmp)
-        assert torch.equal(y3[i * B:(i + 1) * B], want), i
+        if nt >= 13:
+            assert torch.equal(y3[i * B:(i + 1) * B], want), i
+        else:
+            ref = O.blur_images(src.cpu().numpy().astype(np.float64), sigma)
+            np.testing.assert_allclose(y3[i * B:(i + 1) * B].cpu().numpy(), ref, rtol=0, atol=2e-6)
+            np.testing.assert_allclose(y3[i * B:(i + 1) * B].cpu().numpy(), want.cpu().numpy(), rtol=0, atol=1e-6)
     # geometries of other kernels are refused, not silently run elsewhere
-    assert not ops.blur3_lerp_supported(2, 28, 28, 1, 3) and not ops.blur3_lerp_supported(2, 128, 128, 3, 31)
+    assert not ops.blur3_lerp_supported(2, 30, 30, 1, 3) and not ops.blur3_lerp_supported(2, 128, 128, 3, 31)
     with pytest.raises(ValueError):
-        ops.blur3_lerp(f[:, :, :, :1].contiguous().expand(B, H, W, 1).contiguous()[:, :8, :8], r[:, :8, :8, :1].contiguous(), a,
-                       torch.empty(3 * B, 8, 8, 1, device="cuda"), taps, 3)
+        ops.blur3_lerp(torch.zeros(B, 30, 30, 1, device="cuda"), torch.zeros(B, 30, 30, 1, device="cuda"), a,
+                       torch.empty(3 * B, 30, 30, 1, device="cuda"), taps, nt)
 
 
 def test_fused_critic_batch_equals_separate_launches(tmp_path, monkeypatch):
