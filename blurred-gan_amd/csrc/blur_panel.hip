@@ -29,6 +29,10 @@ typedef float floatx3 __attribute__((ext_vector_type(3)));
 constexpr int kPad = 64;            // zeros on either side of the taps in the LDS table
 constexpr int kDepth = 8;           // pass-1 loads in flight per wave
 constexpr int kStagePitch = 100;   // floats per staged output row (96 + 4: float4 rows, 16-byte aligned)
+#ifndef PANEL_PITCH_PAD
+#define PANEL_PITCH_PAD 1
+#endif
+constexpr int kPitchPad = PANEL_PITCH_PAD;   // Y row pitch = 3 W + kPitchPad
 
 struct PanelParams {
   const float* x;
@@ -42,7 +46,7 @@ __global__ __launch_bounds__(512) void blur_panel_kernel(const PanelParams p) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, kk = lane >> 5;
-  const int W = p.W, H = p.H, Q = 3 * W, pitch = Q + 1, T = p.T, half = T >> 1;
+  const int W = p.W, H = p.H, Q = 3 * W, pitch = Q + kPitchPad, T = p.T, half = T >> 1;
   float* Ys = lds;                                  // [32][pitch]
   float* tz = lds + 32 * pitch;                     // [kPad zeros][T taps][kPad zeros]
   // (image, row block).  The panels of an image re-read its rows (a 32-row panel contracts over up to 32 + T - 1 of them), so
@@ -220,7 +224,7 @@ bool blur_panel_ok(int B, int H, int W, int C, int n_taps) {
 
 size_t blur_panel_lds_bytes(int W, int n_taps) {
   // the pass-1 result, the tap table, one 16-row staging slab per wave for the coalesced copy-out
-  return ((size_t)32 * (3 * W + 1) + ((n_taps + 2 * kPad + 3) & ~3) + (size_t)(W / 32) * 16 * kStagePitch + 4) * sizeof(float);
+  return ((size_t)32 * (3 * W + kPitchPad) + ((n_taps + 2 * kPad + 3) & ~3) + (size_t)(W / 32) * 16 * kStagePitch + 4) * sizeof(float);
 }
 
 // MFMA flops the launch issues: 3 tiles x (k-pairs of pass 1, padded to groups of kDepth, + k-pairs of pass 2) per wave

@@ -78,18 +78,26 @@ def init_from_env(backend=None):
 
 
 def _device_identity():
-    """(host, physical card) of this process's current device: uuid where the runtime reports one, else PCI domain:bus:device."""
+    """(host, physical card) of this process's current device: uuid and PCI domain:bus:device as the runtime reports them, or ""
+    when it reports neither (an identity that cannot be told apart must not be mistaken for a shared card)."""
     import socket
     pr = torch.cuda.get_device_properties(torch.cuda.current_device())
-    uuid = getattr(pr, "uuid", None)
-    pci = ":".join(str(getattr(pr, a, "?")) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
-    return f"{socket.gethostname()}|{uuid if uuid is not None else ''}|{pci}"
+    uuid = str(getattr(pr, "uuid", "") or "")
+    if not uuid.strip("0-"):
+        uuid = ""
+    pci_parts = [getattr(pr, a, None) for a in ("pci_domain_id", "pci_bus_id", "pci_device_id")]
+    pci = "" if any(v is None for v in pci_parts) else ":".join(str(v) for v in pci_parts)
+    if not uuid and not pci:
+        return ""
+    return f"{socket.gethostname()}|{uuid}|{pci}"
 
 
 def _distinct_devices(ids):
-    """ids: one identity string per rank.  Raises when two ranks resolved to the same physical card."""
+    """ids: one identity string per rank ("" = unknown, not compared).  Raises when two ranks resolved to the same physical card."""
     seen = {}
     for r, ident in enumerate(ids):
+        if not ident:
+            continue
         if ident in seen:
             raise RuntimeError(f"ranks {seen[ident]} and {r} both run on device {ident}: RCCL ranks sharing a card hang in their "
                                "first collective.  Launch one process per GPU, or give every rank its own device mask "
@@ -105,8 +113,9 @@ def _check_one_device_per_rank(backend):
         return
     store = td.distributed_c10d._get_default_store()
     me, n = td.get_rank(), td.get_world_size()
-    store.set(f"bgan_device_of_rank_{me}", _device_identity())
+    store.set(f"bgan_device_of_rank_{me}", _device_identity() or "?")
     ids = [store.get(f"bgan_device_of_rank_{r}").decode() for r in range(n)]
+    ids = ["" if i == "?" else i for i in ids]
     _distinct_devices(ids)
 
 

@@ -94,6 +94,7 @@ def test_two_ranks_on_one_physical_device_are_refused_not_hung():
     identity of the card each rank ended up on, exchanged through the rendezvous store before the first collective."""
     from blurred_gan_amd import dist
     dist._distinct_devices(["hostA|uuid-1|0:1:0", "hostA|uuid-2|0:2:0", "hostB|uuid-1|0:1:0"])       # same card id on another host: fine
+    dist._distinct_devices(["", "", "hostA|uuid-1|0:1:0", ""])                # a runtime that reports neither uuid nor PCI ids: unknown, never "shared"
     with pytest.raises(RuntimeError, match="ranks 0 and 2 both run on device"):
         dist._distinct_devices(["hostA|uuid-1|0:1:0", "hostA|uuid-2|0:2:0", "hostA|uuid-1|0:1:0"])
 
