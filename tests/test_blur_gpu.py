@@ -76,10 +76,12 @@ def test_small_image_kernels_row_blocks_and_whole_image(shape, std, monkeypatch)
 
 
 @pytest.mark.parametrize("shape,std", [((3, 96, 224, 3), 15.0), ((5, 256, 128, 3), 30.0), ((2, 160, 256, 3), 12.0), ((9, 128, 96, 3), 23.5),
-                                       ((2, 256, 256, 3), 23.5), ((2, 256, 256, 3), 42.34), ((1, 512, 64, 3), 20.0), ((4, 128, 128, 3), 11.2)])
+                                       ((2, 256, 256, 3), 23.5), ((2, 256, 256, 3), 42.34), ((1, 512, 64, 3), 20.0), ((4, 128, 128, 3), 11.2),
+                                       ((8, 96, 128, 3), 12.0), ((16, 160, 96, 3), 14.0), ((40, 96, 96, 3), 12.0)])
 def test_wide_tap_panel_kernel(shape, std, monkeypatch):
     """blur_panel_kernel (> 65 taps, RGB, 32-row panels, both passes in one launch, the pass-1 result in LDS): odd and even panel
-    counts, non-square images, panels whose band is clipped on one side / both sides / not at all, bands wider than the image --
+    counts, non-square images, panels whose band is clipped on one side / both sides / not at all, bands wider than the image,
+    batches that are multiples of 8 (the XCD-aware placement, with and without its reversed image groups) --
     against the float64 oracle, and against the two-launch band passes it replaces (BG_BLUR_NO_PANEL=1)."""
     x = np.random.default_rng(5).uniform(-1, 1, size=shape).astype(np.float32)
     assert O.blur_policy(std, shape[1], shape[2])[2] >= 67
