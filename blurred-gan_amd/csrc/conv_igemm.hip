@@ -203,11 +203,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
       const bool ok = live && (unsigned)(a_y[i] + dy) < (unsigned)p.Hs && (unsigned)(a_x[i] + dx) < (unsigned)p.Ws;
+#if defined(BG_DIAG) && defined(IGEMM_NO_A)
+      rA[i] = make_float4(ok ? 1.f : 0.f, 0.5f, (float)tapoff, 0.25f);      // knock-out: no gather traffic, same data flow
+#else
       rA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_off[i] + tapoff : kOob, 0, 0));
+#endif
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i)
+#if defined(BG_DIAG) && defined(IGEMM_NO_B)
+      rB[i] = make_float4(live ? 1.f : 0.f, 0.5f, (float)woff, 0.25f);
+#else
       rB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_off[i] == kOob || !live) ? kOob : b_off[i] + woff, 0, 0));
+#endif
     --g_left;
     if (++g_kc == kchunks) {
       g_kc = 0;
