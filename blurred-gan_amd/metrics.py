@@ -29,17 +29,23 @@ def calculate_fid_safe(act1: np.ndarray, act2: np.ndarray, epsilon=1e-6) -> floa
     return float(d.dot(d) + np.trace(s1) + np.trace(s2) - 2 * np.trace(covmean))
 
 
-def _nchw_uint_like(x):
-    x = x.detach().cpu().numpy() if hasattr(x, "detach") else np.asarray(x)
-    return x
+def _nchw_uint_like(x, on_device=False):
+    if hasattr(x, "detach"):
+        if on_device and x.is_cuda:
+            return x.detach().to(sw.torch.float32)
+        return x.detach().cpu().numpy()
+    return np.asarray(x)
 
 
 class SWDMetric:
     """metrics.py:93-157.  The reference builds the *fake* descriptors from the real minibatch (metrics.py:131) and never
     sets ``name`` (metrics.py:98); both are fixed here, ``reproduce_reference_bug=True`` restores the former."""
 
-    def __init__(self, name="SWDx1e3_avg", dtype=None, seed=None, reproduce_reference_bug=False):
+    def __init__(self, name="SWDx1e3_avg", dtype=None, seed=None, reproduce_reference_bug=False, on_device=False):
+        """``on_device``: minibatches that arrive as tensors on the GPU stay there (the device path of sliced_wasserstein.py:
+        same draws, float32 rounding apart); the default copies them to the host as the reference's callbacks do."""
         self.name = name
+        self.on_device = on_device
         self.nhood_size, self.nhoods_per_image, self.dir_repeats, self.dirs_per_repeat = 7, 128, 4, 128
         self.resolutions: List[int] = []
         self.rng = np.random.RandomState(seed)
@@ -54,7 +60,7 @@ class SWDMetric:
 
     def update_state(self, real_minibatch, fake_minibatch, *args, **kwargs):
         """Minibatches are NCHW with 3 channels (the callbacks' preprocessing converts, demo_mnist.py:180-184)."""
-        real, fake = _nchw_uint_like(real_minibatch), _nchw_uint_like(fake_minibatch)
+        real, fake = _nchw_uint_like(real_minibatch, self.on_device), _nchw_uint_like(fake_minibatch, self.on_device)
         if not self.resolutions:
             res = real.shape[2]
             while res >= 16:

@@ -73,14 +73,48 @@ def test_reference_golden_checks_on_the_gpu_box():
     cpu.test_api_end_to_end_matches_reference()
 
 
-def test_reference_api_result_with_batches_from_device_memory():
-    """The reference's API result on its golden batches, the batches travelling through device memory as generated samples do."""
+def test_device_path_matches_the_reference_goldens():
+    """N3 on the device: pyramid, descriptor gather, standardisation, projections and sort run on the card (torch tensors in,
+    sliced_wasserstein.py's device branches), draws made on the host from the same RandomState -- held to the outputs of the
+    REFERENCE module (tests/golden/swd_golden.npz), float32 rounding apart."""
     import test_metrics_cpu as cpu
     from blurred_gan_amd import sliced_wasserstein as sw
     G = cpu.G
-    reals = torch.from_numpy(np.ascontiguousarray(G["api_reals"])).cuda()
-    fakes = torch.from_numpy(np.ascontiguousarray(G["api_fakes"])).cuda()
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda()
+    np.testing.assert_allclose(sw.pyr_up(dev(G["small"])).cpu().numpy(), G["small_up"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(sw.pyr_down(dev(G["down_in"])).cpu().numpy(), G["small_down"], rtol=1e-5, atol=1e-6)
+    pyr = sw.generate_laplacian_pyramid(dev(G["batch"]), 2)
+    assert all(p.is_cuda for p in pyr)
+    np.testing.assert_allclose(pyr[0].cpu().numpy(), G["pyr0"], rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(pyr[1].cpu().numpy(), G["pyr1"], rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(sw.reconstruct_laplacian_pyramid(pyr).cpu().numpy(), G["batch"], rtol=1e-4, atol=2e-3)
+    desc = sw.get_descriptors_for_minibatch(dev(G["level"]), 7, 5, np.random.RandomState(4321))
+    assert desc.is_cuda
+    np.testing.assert_array_equal(desc.cpu().numpy(), G["desc"].astype(np.float32))        # a gather: exact
+    np.testing.assert_allclose(sw.finalize_descriptors(desc).cpu().numpy(), G["desc_final"], rtol=1e-5, atol=2e-6)
+    got = sw.sliced_wasserstein(dev(G["A"]), dev(G["B"]), 3, 16, np.random.RandomState(999))
+    assert abs(got - float(G["swd"])) < 1e-5 * max(1.0, abs(float(G["swd"])))
+    assert sw.sliced_wasserstein(dev(G["A"]), dev(G["A"]), 2, 8, np.random.RandomState(1)) == 0.0
     api = sw.API((4, 32, 32, 3), seed=2024)
-    api.begin("reals"); api.feed("reals", reals.cpu().numpy()); api.end("reals")
-    api.begin("fakes"); api.feed("fakes", fakes.cpu().numpy()); res = api.end("fakes")
+    api.begin("reals"); api.feed("reals", dev(G["api_reals"])); api.end("reals")
+    api.begin("fakes"); api.feed("fakes", dev(G["api_fakes"])); res = api.end("fakes")
     np.testing.assert_allclose(res, G["api_result"], rtol=1e-4)
+
+
+def test_swd_metric_on_device_equals_host_metric():
+    """SWDMetric(on_device=True) fed with GPU tensors against the host metric fed with the same images: same draws, same result to
+    float32 rounding."""
+    import test_metrics_cpu as cpu
+    from blurred_gan_amd import metrics
+    G = cpu.G
+    reals = torch.from_numpy(np.ascontiguousarray(G["api_reals"], dtype=np.float32)).cuda()
+    fakes = torch.from_numpy(np.ascontiguousarray(G["api_fakes"], dtype=np.float32)).cuda()
+    md, mh = metrics.SWDMetric(seed=7, on_device=True), metrics.SWDMetric(seed=7)
+    for m, r, f in ((md, reals, fakes), (mh, reals.cpu().numpy(), fakes.cpu().numpy())):
+        m.update_state(r, f)
+        m.update_state(r.flip(0) if hasattr(r, "flip") else r[::-1].copy(), f)
+    assert all(d.is_cuda for lst in md.real_descriptors for d in lst)
+    rd, rh = md.results(), mh.results()
+    assert rd.keys() == rh.keys()
+    for k in rd:
+        assert abs(rd[k] - rh[k]) <= 1e-4 * max(1.0, abs(rh[k])), (k, rd[k], rh[k])
