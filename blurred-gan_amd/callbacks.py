@@ -236,9 +236,11 @@ class FeedImagesToMetricCallback(ExecuteEveryNExamplesCallback):
 class SWDMetricCallback(FeedImagesToMetricCallback):
     """callbacks.py:186-198 (the reference's ``write_result`` reads an undefined ``self.swd_metric``; fixed)."""
 
-    def __init__(self, image_preprocessing_fn, num_samples=1000, every_n_examples=10_000, seed=None):
+    def __init__(self, image_preprocessing_fn, num_samples=1000, every_n_examples=10_000, seed=None, on_device=False):
+        """``on_device``: the preprocessed minibatches (device tensors) are not copied to the host; the metric's device path runs."""
         from .metrics import SWDMetric
-        super().__init__(SWDMetric(seed=seed), image_preprocessing_fn, num_samples=num_samples, every_n_examples=every_n_examples)
+        super().__init__(SWDMetric(seed=seed, on_device=on_device), image_preprocessing_fn, num_samples=num_samples,
+                         every_n_examples=every_n_examples)
 
     def write_result(self):
         results = self.metric.results()

@@ -118,3 +118,23 @@ def test_swd_metric_on_device_equals_host_metric():
     assert rd.keys() == rh.keys()
     for k in rd:
         assert abs(rd[k] - rh[k]) <= 1e-4 * max(1.0, abs(rh[k])), (k, rd[k], rh[k])
+
+
+def test_swd_callback_on_device_in_a_real_fit(tmp_path):
+    """SWDMetricCallback(on_device=True) beside the host one in the same fit(): same images, same seeds, same numbers to rounding."""
+    import blurred_gan_amd as bg
+    from blurred_gan_amd import models, callbacks
+    bg.set_seed(3)
+    B, nb = 8, 4
+    gen, disc = models.DCGANGenerator(arch="mnist"), models.DCGANDiscriminator(arch="mnist")
+    hp = bg.BlurredWGANGP.HyperParameters(initial_blur_std=1.0, global_batch_size=B, batch_size=B)
+    gan = bg.BlurredWGANGP(gen, disc, hp, bg.TrainingConfig(log_dir=str(tmp_path / "log")))
+    g = torch.Generator().manual_seed(2)
+    data = [torch.rand(B, 28, 28, 1, generator=g) * 2 - 1 for _ in range(nb)]
+    host = callbacks.SWDMetricCallback(_preprocess, num_samples=2 * B, every_n_examples=2 * B, seed=5)
+    dev = callbacks.SWDMetricCallback(_preprocess, num_samples=2 * B, every_n_examples=2 * B, seed=5, on_device=True)
+    gan.fit(data, epochs=1, callbacks=[host, dev])
+    assert len(host.results) == len(dev.results) >= 1
+    for rh, rd in zip(host.results, dev.results):
+        for k in rh:
+            assert abs(rh[k] - rd[k]) <= 1e-4 * max(1.0, abs(rh[k])), (k, rh[k], rd[k])
