@@ -31,6 +31,7 @@ struct bg_program {
 
   ~bg_program() { drop_graphs(); }
   void drop_graphs() {
+    if (!graphs.empty()) (void)hipDeviceSynchronize();      // an executable graph may still be running (eviction right after a launch)
     for (auto& kv : graphs) {
       if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
       if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
