@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-SHAPES = {"tiny": (8, 8, 3), "mnist": (28, 28, 1), "celeba64": (64, 64, 3)}
+SHAPES = {"tiny": (8, 8, 3), "mnist": (28, 28, 1), "celeba64": (64, 64, 3), "celeba128": (128, 128, 3)}
 
 
 def _make(arch, B, seed, tmp_path, replay, sigma0, **kw):
@@ -33,6 +33,7 @@ def _same_state(a, b):
     ("tiny", 4, [0.9, 0.88, 0.86, 0.84, 0.82, 0.5, 0.49, 0.48, 0.47]),             # 5 taps ... then 3 taps: a second program
     ("mnist", 8, [2.0, 1.98, 1.96, 1.94, 1.92, 1.9, 1.0, 0.99, 0.98, 0.97]),       # 13 taps ... then 7
     ("celeba64", 8, [5.0, 4.99, 4.98, 4.97, 4.96, 4.95]),                            # 31 taps throughout
+    ("celeba128", 4, [5.0, 4.99, 4.98, 4.97, 4.96]),                                 # the verbatim 128-pixel stacks (16-channel kernels)
 ])
 def test_replayed_steps_equal_eager_steps_bit_for_bit(tmp_path, arch, B, sigmas):
     eager = _make(arch, B, 21, tmp_path, False, sigmas[0])
