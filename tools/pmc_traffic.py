@@ -60,6 +60,20 @@ def main():
                 alg = e.get("alg_mb") or 0.0
                 fh.write(f"| {i} {e['kernel']} ({e['gflop']} GFLOP) | `{sym[:60]}` | {e['us']} | {alg:.1f} | {hbm:.1f} | {hbm / alg if alg else float('nan'):.2f} |\n")
         print(open(out + ".wgrad.md").read())
+    # ---- gather-GEMM launches, launch by launch (round 4): where the dominant kernel's excess over its algorithmic bytes sits
+    gtags = [e for e in full if e["kernel"] in ("conv_igemm_fwd", "conv_igemm_dgrad")]
+    isg = lambda n: "conv_igemm_kernel" in n
+    fd = [(n, v) for n, v in dispatches(fdir, "FETCH_SIZE") if isg(n)]
+    wd = [(n, v) for n, v in dispatches(wdir, "WRITE_SIZE") if isg(n)]
+    if gtags and len(fd) >= len(gtags) and len(wd) >= len(gtags):
+        fd, wd = fd[-len(gtags):], wd[-len(gtags):]
+        with open(out + ".igemm.md", "w") as fh:
+            fh.write("| launch (step order) | tile | us | GFLOP | algorithmic MB | fetch x2 MB | write MB | HBM-side MB | ratio |\n|---|---|---|---|---|---|---|---|---|\n")
+            for i, (e, (fn, fv), (_, wv)) in enumerate(zip(gtags, fd, wd)):
+                f2, w = fv * 2.0 * 1024.0 / 1e6, wv * 1024.0 / 1e6
+                tile = fn.split("conv_igemm_kernel<")[1].split(">")[0] if "conv_igemm_kernel<" in fn else "?"
+                alg = e.get("alg_mb") or 0.0
+                fh.write(f"| {i} {e['kernel']} | {tile} | {e['us']} | {e['gflop']} | {alg:.1f} | {f2:.1f} | {w:.1f} | {f2 + w:.1f} | {(f2 + w) / alg if alg else float('nan'):.2f} |\n")
 
 
 if __name__ == "__main__":
