@@ -29,6 +29,62 @@ PEAK_HBM_GBS = 8000.0
 CONV_GFLOP_PER_IMAGE = {"celeba64": 3.908, "celeba128": 4.769, "mnist": 0.659}
 
 
+def same_live_taps(n, k=5, s=2):
+    """(output position, tap) pairs of a 1-D k-tap stride-s TF-SAME window over n samples whose source sample exists (is not zero
+    padding): out = ceil(n/s), pad_total = max((out-1)s + k - n, 0), pad_before = pad_total // 2 (SURVEY 8a row T1)."""
+    o = -(-n // s)
+    before = max((o - 1) * s + k - n, 0) // 2
+    return sum(1 for i in range(o) for t in range(k) if 0 <= i * s + t - before < n)
+
+
+def conv_layers(arch):
+    """The conv / transposed-conv / dense layers of both stacks as (net, kind, H, W, Cin, Cout, stride): conv INPUT-side geometry
+    (a Conv2DTranspose is listed as the convolution it is the data gradient of, i.e. H, W = its output side), dense as
+    (net, "dense", 1, 1, in, out, 1).  demo_celeba.py:51-124, demo_mnist.py:48-86."""
+    from blurred_gan_amd import models
+    base, ch, convt, last = models._G[arch]
+    out = [("G", "dense", 1, 1, models.LATENT[arch], base * base * ch, 1)]
+    hw, c = base, ch
+    for filters, stride, _ in convt:
+        hw *= stride
+        out.append(("G", "convt", hw, hw, filters, c, stride))
+        c = filters
+    if last is not None:
+        out.append(("G", "conv", hw, hw, c, last, 1))
+    H, W, C = models.IMAGE_SHAPE[arch]
+    hw, c = H, C
+    for f in models._D[arch]:
+        out.append(("D", "conv", hw, hw, c, f, 2))
+        hw, c = -(-hw // 2), f
+    out.append(("D", "dense", 1, 1, hw * hw * c, 1, 1))
+    return out
+
+
+def conv_macs_per_image(arch, useful=False):
+    """Forward-MAC equivalents of one train_on_batch per image: generator 4 passes (D-step forward, G-step forward,
+    data gradient, filter gradient; its Dense has no data gradient), critic 12 (D-step: 3 forwards, 2 x (filter + data gradient),
+    the penalty's data-gradient chain, its linearised forward and filter gradient; G-step: forward + data gradient), the first
+    critic conv 10 (no data gradient to the image on the [fakes; reals] rows).  useful=False: F_l = Ho*Wo*Cin*Cout*25 (every tap at
+    every output position); useful=True: only the (output pixel, tap) pairs whose source pixel exists --
+    the taps on TF's zero padding multiply nothing."""
+    total, first_d = 0, True
+    for net, kind, H, W, Ci, Co, s in conv_layers(arch):
+        if kind == "dense":
+            f = Ci * Co
+            total += (3 if net == "G" else 12) * f
+            continue
+        if useful:
+            f = same_live_taps(H, 5, s) * same_live_taps(W, 5, s) * Ci * Co
+        else:
+            f = (-(-H // s)) * (-(-W // s)) * Ci * Co * 25
+        if net == "G":
+            total += 4 * f
+        else:
+            total += (10 if first_d else 12) * f
+            first_d = False
+    return total
+
+
 def build_gan(arch, B, world, sigma):
     import blurred_gan_amd as bg
     from blurred_gan_amd import models, dist
@@ -303,6 +359,7 @@ def main():
     dt = time.perf_counter() - t0
     dt = dist.max_over_ranks(dt)
     value = B * world * args.steps / dt
+    dp_evidence = dist.evidence()          # every rank takes part (an all-reduce and an all-gather through the step's communicator)
 
     # ---- per-kernel HIP-event timing on the launch stream (separate, un-timed steps)
     roof = None
@@ -314,36 +371,55 @@ def main():
         for _ in range(nprof):
             step()
         torch.cuda.synchronize()
-        recs = ops.prof_records(with_exec=True)
+        recs = ops.prof_records(with_exec=True, with_useful=True)
         ops.prof_enable(False)
         ops.prof_reset()
-        for name, ms, fl, by, ex in recs:
-            k = kern.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0])
-            k[0] += 1; k[1] += ms; k[2] += fl; k[3] += by; k[4] += ex
+        for name, ms, fl, by, ex, us in recs:
+            k = kern.setdefault(name, [0, 0.0, 0.0, 0.0, 0.0, 0.0])
+            k[0] += 1; k[1] += ms; k[2] += fl; k[3] += by; k[4] += ex; k[5] += us
         # every conv kernel family runs on the MFMA pipe (gather-GEMM, row-staged, filter-gradient) except the direct fallback;
         # their split-K / slab reduce passes are counted with them
         mfma = {n: k for n, k in kern.items() if n.startswith("conv_") and n != "conv_wgrad_direct"}
         if mfma:
             dom = max(mfma, key=lambda n: mfma[n][1])
-            cnt, ms, fl, by, ex = mfma[dom]
+            cnt, ms, fl, by, ex, us = mfma[dom]
             ach = fl / (ms * 1e-3) / 1e12
             ach_x = ex / (ms * 1e-3) / 1e12
+            ach_u = us / (ms * 1e-3) / 1e12
             traffic = hbm_traffic(dom, args.arch, B)
             all_ms = sum(k[1] for k in mfma.values())
             all_fl = sum(k[2] for k in mfma.values())
+            all_us = sum(k[5] for k in mfma.values())
+            # the step's convolution work per image, both counts, from the closed forms (the per-launch records of the library
+            # must add up to them: checked below and in tests/test_bench_cpu.py)
+            gf_alg = 2e-9 * conv_macs_per_image(args.arch)
+            gf_use = 2e-9 * conv_macs_per_image(args.arch, useful=True)
             roof = {"bound": "mfma", "kernel": dom, "achieved": round(ach, 3), "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / PEAK_MFMA_F32_TFLOPS, 4),
                     # the same launches priced by the MFMA flops they ISSUE: whole tiles (padding rows / columns in), minus the
                     # zero-padding taps that position-major tiles skip -- how busy the matrix pipe is, not how useful
                     "executed": {"achieved": round(ach_x, 3), "frac": round(ach_x / PEAK_MFMA_F32_TFLOPS, 4)},
+                    # ... and by the flops that multiply REAL data: SURVEY 8d's count above charges all 25 taps at every output
+                    # position, but on a 4x4 map 51 % of them (8x8: 28 %) land on the SAME zero padding and are work nobody has to
+                    # do (bg_prof_get_useful: exact (output pixel, tap) pairs inside the image, no tile padding).  This is the
+                    # figure that cannot read above 1; "frac" keeps SURVEY 8d's definition.
+                    "useful": {"achieved": round(ach_u, 3), "frac": round(ach_u / PEAK_MFMA_F32_TFLOPS, 4),
+                               "share_of_algorithmic": round(us / fl, 4) if fl else None},
                     "traffic": traffic,
                     "traffic_unit": f"HBM-side bytes per launch (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, {TRAFFIC_FILE})" if traffic else None,
                     "algorithmic_bytes_per_launch": round(by / cnt) if by else None,
                     "launches_per_step": cnt // nprof, "avg_launch_ms": round(ms / cnt, 5),
                     "all_mfma_kernels": {"achieved": round(all_fl / (all_ms * 1e-3) / 1e12, 3),
                                          "frac": round(all_fl / (all_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
+                                         "useful_frac": round(all_us / (all_ms * 1e-3) / 1e12 / PEAK_MFMA_F32_TFLOPS, 4),
                                          "ms_per_step": round(all_ms / nprof, 4)},
-                    "step_conv_frac": round(CONV_GFLOP_PER_IMAGE[args.arch] * value / world / 1e3 / PEAK_MFMA_F32_TFLOPS, 4)}
+                    "step_conv_frac": round(CONV_GFLOP_PER_IMAGE[args.arch] * value / world / 1e3 / PEAK_MFMA_F32_TFLOPS, 4),
+                    "step_conv_frac_useful": round(gf_use * value / world / 1e3 / PEAK_MFMA_F32_TFLOPS, 4),
+                    "conv_gflop_per_image": {"algorithmic": round(gf_alg, 4), "useful": round(gf_use, 4),
+                                             # what the library's per-launch records of one step add up to (conv launches only;
+                                             # the closed forms also hold the Dense layers, ~0.1 % of the total)
+                                             "recorded_algorithmic": round(all_fl / nprof / B / 1e9, 4),
+                                             "recorded_useful": round(all_us / nprof / B / 1e9, 4)}}
 
     if dist.rank() == 0:
         out = {"metric": "images/sec (G+D+GP step)", "value": round(value, 2), "unit": "images/s", "n_gpus": world,
@@ -352,6 +428,10 @@ def main():
                "config": {"workload": f"{args.arch} {H}x{W}x{C} batch {B}/GPU, blur sigma {args.sigma} "
                                       f"({ops.blur_policy(float(gan.std), H, W)[2]} taps), D-step+GP+G-step+Adam",
                           "global_batch": B * world, "parallelism": f"dp{world}"}}
+        if dp_evidence:
+            # the collective layer's own account of the group: peers counted by an all-reduce through the communicator the
+            # gradients use, every rank's physical card -- so that an N-GPU line shows N ranks on N distinct devices over RCCL
+            out["dp"] = dp_evidence
         if roof is not None:
             out["roofline"] = roof
         if kern:
@@ -360,7 +440,8 @@ def main():
         if kern and args.kernels_out:
             table = [{"kernel": n, "launches_per_step": k[0] / 2, "ms_per_step": round(k[1] / 2, 5),
                       "tflops": round(k[2] / (k[1] * 1e-3) / 1e12, 2) if k[2] else None} for n, k in sorted(kern.items(), key=lambda kv: -kv[1][1])]
-            seq = [{"kernel": n, "us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 3), "alg_mb": round(by / 1e6, 3)} for n, ms, fl, by, _ in recs[:len(recs) // 2]]
+            seq = [{"kernel": n, "us": round(ms * 1e3, 2), "gflop": round(fl / 1e9, 3), "useful_gflop": round(us / 1e9, 3), "alg_mb": round(by / 1e6, 3)}
+                   for n, ms, fl, by, _, us in recs[:len(recs) // 2]]
             with open(args.kernels_out, "w") as f:
                 json.dump({"ms_per_step_sum": round(sum(k[1] for k in kern.values()) / 2, 4), "kernels": table, "sequence": seq}, f, indent=1)
         if world == 1 and not args.no_cpu_baseline:

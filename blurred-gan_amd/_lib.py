@@ -19,7 +19,7 @@ class Epilogue(C.Structure):
                 ("keep_elems", C.c_size_t), ("stats", C.c_void_p), ("stats_capacity", C.c_size_t), ("stats_rows", C.POINTER(C.c_int))]
 
 
-ABI_VERSION = 4           # include/bgan.h BG_ABI_VERSION
+ABI_VERSION = 5           # include/bgan.h BG_ABI_VERSION
 EPI_NONE, EPI_BIAS_LRELU, EPI_MUL_GRAD, EPI_TANH, EPI_AFFINE_LRELU = 0, 1, 2, 3, 4
 
 _p, _i, _f, _z, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_uint64
@@ -34,6 +34,8 @@ SIGNATURES = {
     "bg_prof_count": (_i, []),
     "bg_prof_get": (_i, [_i, C.c_char_p, _i, C.POINTER(_f), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "bg_prof_get_exec": (_i, [_i, C.POINTER(C.c_double)]),
+    "bg_prof_get_useful": (_i, [_i, C.POINTER(C.c_double)]),
+    "bg_conv2d_useful_flops": (C.c_double, [_i] * 7),
     "bg_range_enable": (_i, [_i]),
     "bg_range_push": (_i, [C.c_char_p]),
     "bg_range_pop": (_i, []),
@@ -101,6 +103,7 @@ SIGNATURES = {
     "bg_comm_unique_id": (_i, [C.c_char_p]),
     "bg_comm_init": (_i, [C.POINTER(_p), _i, _i, C.c_char_p]),
     "bg_allreduce_sum_f32": (_i, [_p, _p, _z, _p]),
+    "bg_comm_query": (_i, [_p, C.POINTER(_i), C.POINTER(_i)]),
     "bg_comm_destroy": (_i, [_p]),
 }
 

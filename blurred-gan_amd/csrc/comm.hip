@@ -15,6 +15,8 @@ struct Rccl {
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int*) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int*) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
@@ -37,6 +39,8 @@ int bind_rccl() {
   r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(h, "ncclAllReduce"));
   r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
   r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+  r.CommCount = reinterpret_cast<decltype(r.CommCount)>(dlsym(h, "ncclCommCount"));            // optional (bg_comm_query)
+  r.CommUserRank = reinterpret_cast<decltype(r.CommUserRank)>(dlsym(h, "ncclCommUserRank"));
   if (!r.GetUniqueId || !r.CommInitRank || !r.AllReduce || !r.CommDestroy || !r.GetErrorString) {
     dlclose(h);
     return bg::fail(BG_ERR_RCCL, "bg_comm: librccl lacks a required symbol");
@@ -86,6 +90,20 @@ int bg_allreduce_sum_f32(bg_comm* comm, float* buf_d, size_t n, void* stream) {
   BG_REQUIRE(n > 0, BG_ERR_BAD_SHAPE, "bg_allreduce_sum_f32: empty buffer");
   ncclResult_t e = g_rccl.AllReduce(buf_d, buf_d, n, ncclFloat32, ncclSum, comm->comm, static_cast<hipStream_t>(stream));
   if (e != ncclSuccess) return rccl_fail("ncclAllReduce", e);
+  return BG_OK;
+}
+
+int bg_comm_query(bg_comm* comm, int* nranks, int* rank) {
+  BG_REQUIRE(comm, BG_ERR_NULL, "bg_comm_query: null communicator");
+  int n = comm->nranks, r = comm->rank;
+  if (g_rccl.CommCount && g_rccl.CommUserRank) {            // what RCCL itself says, not what the caller passed to bg_comm_init
+    ncclResult_t e = g_rccl.CommCount(comm->comm, &n);
+    if (e != ncclSuccess) return rccl_fail("ncclCommCount", e);
+    e = g_rccl.CommUserRank(comm->comm, &r);
+    if (e != ncclSuccess) return rccl_fail("ncclCommUserRank", e);
+  }
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
   return BG_OK;
 }
 

@@ -16,6 +16,34 @@ bool prof_on();
 void prof_begin(hipStream_t s, const char* name, double flops, double bytes);
 void prof_end(hipStream_t s);
 void prof_exec_flops(double f);      // flops the launch ISSUES on the matrix pipe (tile padding in, skipped padding taps out)
+void prof_useful_flops(double f);    // flops of the launch that multiply real data: no zero-padding taps, no tile padding
+// The conv entry points announce the USEFUL flop count of the call (conv_useful_flops) before they dispatch; the first launch
+// bracket of the call that carries flops takes it (every conv call has exactly one such launch; its reduce passes carry none).
+void set_pending_useful(double f);   // < 0 clears
+double take_pending_useful();        // returns and clears; < 0 when nothing is pending
+
+// Exact multiply-accumulates x 2 of a k x k / stride-s SAME convolution over real data (SURVEY 8d's F_l charges every tap at every
+// output position; the taps that fall on TF's zero padding multiply nothing).  The same (output pixel, tap) pairs are touched by
+// the forward, the data gradient / transposed convolution and the filter gradient of the geometry, so one count serves all three.
+// H, W, Cin: conv input side (for a Conv2DTranspose: its OUTPUT side).
+inline double conv_useful_flops(int B, int H, int W, int Cin, int Cout, int k, int s) {
+  auto live = [&](int n) {
+    const int o = (n + s - 1) / s;
+    int tot = (o - 1) * s + k - n;
+    if (tot < 0) tot = 0;
+    const int before = tot / 2;
+    long c = 0;
+    for (int i = 0; i < o; ++i)
+      for (int t = 0; t < k; ++t) c += ((unsigned)(i * s + t - before) < (unsigned)n) ? 1 : 0;
+    return c;
+  };
+  return 2.0 * B * (double)Cin * Cout * (double)live(H) * (double)live(W);
+}
+
+struct UsefulScope {                 // RAII: a conv entry point's announcement never outlives the call
+  explicit UsefulScope(double f) { set_pending_useful(f); }
+  ~UsefulScope() { set_pending_useful(-1.0); }
+};
 
 inline int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -43,6 +71,14 @@ struct Launch {
     prof = live || rec;
     if (live) prof_begin(s, name, flops, bytes);
     if (rec) rec_note(1, name, flops, bytes);
+    if (prof && flops > 0) {
+      const double u = take_pending_useful();
+      if (u >= 0) useful_flops(u);
+    }
+  }
+  void useful_flops(double f) {
+    if (live) prof_useful_flops(f);
+    if (rec) rec_note(4, nullptr, f, 0);
   }
   void exec_flops(double f) {
     if (live) prof_exec_flops(f);

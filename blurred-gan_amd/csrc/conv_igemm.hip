@@ -226,10 +226,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
   auto lstore = [&](int buf, const float4 (&rA)[AP], const float4 (&rB)[BP]) {
     float* sa = smem + buf * STAGE;
     float* sb = sa + BM * LD;
+#if defined(BG_DIAG) && defined(IGEMM_NO_LSTORE)
+    // knock-out: the staged tiles are consumed (the loads stay live and waited for) but never written to LDS
+#pragma unroll
+    for (int i = 0; i < AP; ++i) asm volatile("" ::"v"(rA[i].x), "v"(rA[i].y), "v"(rA[i].z), "v"(rA[i].w));
+#pragma unroll
+    for (int i = 0; i < BP; ++i) asm volatile("" ::"v"(rB[i].x), "v"(rB[i].y), "v"(rB[i].z), "v"(rB[i].w));
+    (void)sa; (void)sb;
+#else
 #pragma unroll
     for (int i = 0; i < AP; ++i) *reinterpret_cast<float4*>(sa + (lrow + i * RPP) * LD + lq * 4) = rA[i];
 #pragma unroll
     for (int i = 0; i < BP; ++i) *reinterpret_cast<float4*>(sb + (lrow + i * RPP) * LD + lq * 4) = rB[i];
+#endif
   };
 
   floatx16 acc[MI][NI];
@@ -261,6 +270,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
   // fragments: 4 k's per b128 read, fetched one k-octet ahead of the MFMAs that consume them, across step boundaries
   float4 af[2][MI], bf[2][NI];
   auto fetch = [&](int slot, int buf, int ko) {
+#if defined(BG_DIAG) && defined(IGEMM_NO_FETCH)
+    if (ko >= 0) {                           // knock-out: no fragment reads in the loop (registers keep their first contents)
+      asm volatile("" : "+v"(af[slot][0].x), "+v"(bf[slot][0].x));
+      return;
+    }
+#endif
     const float* sa = sa0 + buf * STAGE + ko * 8;
     const float* sb = sb0 + buf * STAGE + ko * 8;
 #pragma unroll
@@ -268,6 +283,15 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
 #pragma unroll
     for (int j = 0; j < NI; ++j) bf[slot][j] = *reinterpret_cast<const float4*>(sb + j * 32 * LD);
   };
+#if defined(BG_DIAG) && defined(IGEMM_NO_FETCH)
+#pragma unroll
+  for (int sl = 0; sl < 2; ++sl) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) af[sl][i] = make_float4(1.f, 0.5f, 0.25f, 2.f);
+#pragma unroll
+    for (int j = 0; j < NI; ++j) bf[sl][j] = make_float4(0.5f, 1.f, 2.f, 0.25f);
+  }
+#endif
   fetch(0, 0, 0);
   // one pipeline step on LDS buffer `cur`; `mid` (ds_write of the next tile, loads of a later one) runs before the barrier
   auto step_body = [&](int cur, auto mid) {
@@ -277,7 +301,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
       if (ko + 1 < KO) fetch(n, cur, ko + 1);
       if (ko == KO / 2) {
         mid();
+#if !(defined(BG_DIAG) && defined(IGEMM_NO_BARRIER))
         __syncthreads();                      // tile `cur^1` complete; every read of tile `cur` was issued (and drained) before it
+#endif
       }
       if (ko + 1 == KO) fetch(n, cur ^ 1, 0);
       __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ahead of the MFMAs (see conv_wgrad.hip)
@@ -333,6 +359,19 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
     }
   };
   auto epilogue = [&](int q) {
+#if defined(BG_DIAG) && defined(IGEMM_NO_EPI)
+    {                                          // knock-out: nothing stored, nothing read; the accumulators stay live and restart
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j) {
+          asm volatile("" : "+v"(acc[i][j]));
+#pragma unroll
+          for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        }
+      return;
+    }
+#endif
     if (TR) {
       epilogue_tr(q);
       return;
@@ -1221,6 +1260,7 @@ int bg_conv2d_fwd(const float* x, const float* wT_d, float* y, int B, int H, int
   if (epi && epi->stats_rows) *epi->stats_rows = 0;
   int rc = check_conv_args("bg_conv2d_fwd", x, wT_d, y, B, H, W, Cin, Cout, ksize, stride);
   if (rc) return rc;
+  bg::UsefulScope useful(bg::conv_useful_flops(B, H, W, Cin, Cout, ksize, stride));
   int taken = 0;
   rc = bg::try_conv_c16(0, x, wT_d, y, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
   if (rc || taken) return rc;
@@ -1240,6 +1280,7 @@ int bg_conv2d_bwd_data(const float* dy, const float* w_d, float* dx, int B, int 
   if (epi && epi->stats_rows) *epi->stats_rows = 0;
   int rc = check_conv_args("bg_conv2d_bwd_data", dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride);
   if (rc) return rc;
+  bg::UsefulScope useful(bg::conv_useful_flops(B, H, W, Cin, Cout, ksize, stride));
   int taken = 0;
   rc = bg::try_conv_c16(1, dy, w_d, dx, B, H, W, Cin, Cout, ksize, stride, epi, stream, &taken);
   if (rc || taken) return rc;

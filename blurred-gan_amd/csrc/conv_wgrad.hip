@@ -1676,6 +1676,7 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
   BG_REQUIRE(ksize >= 1 && (ksize & 1) && ksize * ksize <= bg::kMaxTaps, BG_ERR_UNSUPPORTED, "bg_conv2d_bwd_filter: kernel size %d", ksize);
   BG_REQUIRE(stride == 1 || stride == 2, BG_ERR_UNSUPPORTED, "bg_conv2d_bwd_filter: stride %d", stride);
   BG_REQUIRE(bg::aligned16(x) && bg::aligned16(dy) && bg::aligned16(dw), BG_ERR_BAD_ALIGNMENT, "bg_conv2d_bwd_filter: pointers must be 16-byte aligned");
+  bg::UsefulScope useful(bg::conv_useful_flops(B, H, W, Cin, Cout, ksize, stride));
   WgradPlan pl = plan_wgrad(B, H, W, Cin, Cout, ksize, stride);
   const size_t nout = (size_t)ksize * ksize * Cin * Cout;
   const bool slabs = pl.ksplit > 1 || pl.always_slab;

@@ -17,7 +17,7 @@ namespace bg {
 
 struct Node {
   virtual ~Node() {}
-  // kind 0: kernel launch, 1: profiling bracket begin, 2: end, 3: executed-flops note
+  // kind 0: kernel launch, 1: profiling bracket begin, 2: end, 3: executed-flops note, 4: useful-flops note
   int kind = 0;
   virtual hipError_t run(hipStream_t) { return hipSuccess; }
   virtual void* arg_ptr(int) { return nullptr; }

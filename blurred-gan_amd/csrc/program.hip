@@ -28,10 +28,15 @@ struct bg_program {
   std::map<std::pair<int, int>, GraphForm> graphs;
   int launches = 0;
   bool recording = false;
+  hipStream_t graph_stream = nullptr;     // the stream the last bg_program_graph_launch went to
+  bool graph_launched = false;
 
   ~bg_program() { drop_graphs(); }
   void drop_graphs() {
-    if (!graphs.empty()) (void)hipDeviceSynchronize();      // an executable graph may still be running (eviction right after a launch)
+    // an executable graph may still be running (eviction right after a launch): wait for the stream it was launched on -- not for
+    // the device; the library promises no hidden device-wide synchronisation (include/bgan.h "Threading / async")
+    if (!graphs.empty() && graph_launched) (void)hipStreamSynchronize(graph_stream);
+    graph_launched = false;
     for (auto& kv : graphs) {
       if (kv.second.exec) (void)hipGraphExecDestroy(kv.second.exec);
       if (kv.second.graph) (void)hipGraphDestroy(kv.second.graph);
@@ -55,6 +60,7 @@ namespace {
 thread_local bg_program* t_rec = nullptr;
 thread_local int t_pending_what[4] = {0, 0, 0, 0};
 thread_local int t_pending_slot[4] = {-1, -1, -1, -1};
+thread_local bool t_bind_failed = false;       // a bind_last() that did not fit its node: reported by bg_program_record_end
 }  // namespace
 
 bool recording() { return t_rec != nullptr; }
@@ -91,7 +97,13 @@ void bind_last(int arg_index, BindKind kind, int slot) {
   const int node = (int)t_rec->nodes.size() - 1;
   Node* n = t_rec->nodes[node].get();
   const size_t want = kind == BIND_F32_FROM_F64 ? sizeof(float) : sizeof(uint64_t);
-  if (n->kind != 0 || n->arg_size(arg_index) != want) return;      // guarded by the CPU test on the binding table
+  if (n->kind != 0 || n->arg_size(arg_index) != want) {
+    // a silently dropped binding would replay the recording step's lr_t / Philox offset for ever: fail the recording instead
+    set_error("step program: binding of slot %d to argument %d of node %d does not fit (node kind %d, argument size %zu, wanted %zu)",
+              slot, arg_index, node, n->kind, n->arg_size(arg_index), want);
+    t_bind_failed = true;
+    return;
+  }
   t_rec->binds.push_back({node, arg_index, (int)kind, slot});
 }
 
@@ -124,6 +136,7 @@ int bg_program_record_begin(bg_program* p) {
   p->launches = 0;
   p->recording = true;
   for (int i = 0; i < 4; ++i) bg::t_pending_slot[i] = -1;
+  bg::t_bind_failed = false;
   bg::t_rec = p;
   return BG_OK;
 }
@@ -133,6 +146,10 @@ int bg_program_record_end(bg_program* p) {
   BG_REQUIRE(bg::t_rec == p, BG_ERR_UNSUPPORTED, "bg_program_record_end: this program is not the one being recorded");
   bg::t_rec = nullptr;
   p->recording = false;
+  if (bg::t_bind_failed) {
+    bg::t_bind_failed = false;
+    return BG_ERR_UNSUPPORTED;          // message left by bind_last
+  }
   for (int i = 0; i < 4; ++i)
     BG_REQUIRE(bg::t_pending_slot[i] < 0, BG_ERR_UNSUPPORTED,
                "bg_program_record_end: a binding (what=%d) was announced but no launch consumed it", bg::t_pending_what[i]);
@@ -181,6 +198,7 @@ int bg_program_replay(bg_program* p, int first, int last, void* stream) {
       if (nd->kind == 1) bg::prof_begin(s, nn->name.c_str(), nn->a, nn->b);
       else if (nd->kind == 2) bg::prof_end(s);
       else if (nd->kind == 3) bg::prof_exec_flops(nn->a);
+      else if (nd->kind == 4) bg::prof_useful_flops(nn->a);
     }
   }
   return BG_OK;
@@ -252,6 +270,8 @@ int bg_program_graph_launch(bg_program* p, int first, int last, void* stream) {
     }
   }
   BG_HIP(hipGraphLaunch(it->second.exec, s));
+  p->graph_stream = s;
+  p->graph_launched = true;
 #undef BG_HIP
   return BG_OK;
 }

@@ -18,7 +18,7 @@ void set_error(const char* fmt, ...) {
 
 struct ProfRec {
   std::string name;
-  double flops, bytes, exec_flops;
+  double flops, bytes, exec_flops, useful_flops;
   hipEvent_t e0, e1;
 };
 static bool g_prof = false;
@@ -34,6 +34,7 @@ void prof_begin(hipStream_t s, const char* name, double flops, double bytes) {
   r.flops = flops;
   r.bytes = bytes;
   r.exec_flops = flops;          // until the launcher says otherwise (prof_exec_flops)
+  r.useful_flops = flops;        // likewise (prof_useful_flops)
   (void)hipEventCreate(&r.e0);
   (void)hipEventCreate(&r.e1);
   (void)hipEventRecord(r.e0, s);
@@ -43,6 +44,19 @@ void prof_begin(hipStream_t s, const char* name, double flops, double bytes) {
 void prof_exec_flops(double f) {
   std::lock_guard<std::mutex> lk(g_mu);
   if (!g_recs.empty()) g_recs.back().exec_flops = f;
+}
+
+void prof_useful_flops(double f) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_recs.empty()) g_recs.back().useful_flops = f;
+}
+
+static thread_local double g_pending_useful = -1.0;
+void set_pending_useful(double f) { g_pending_useful = f; }
+double take_pending_useful() {
+  const double f = g_pending_useful;
+  g_pending_useful = -1.0;
+  return f;
 }
 
 void prof_end(hipStream_t s) {
@@ -151,6 +165,18 @@ int bg_prof_get_exec(int i, double* exec_flops) {
   if (i < 0 || i >= (int)bg::g_recs.size()) return bg::fail(BG_ERR_BAD_SHAPE, "bg_prof_get_exec: index %d out of range", i);
   if (exec_flops) *exec_flops = bg::g_recs[i].exec_flops;
   return BG_OK;
+}
+
+int bg_prof_get_useful(int i, double* useful_flops) {
+  std::lock_guard<std::mutex> lk(bg::g_mu);
+  if (i < 0 || i >= (int)bg::g_recs.size()) return bg::fail(BG_ERR_BAD_SHAPE, "bg_prof_get_useful: index %d out of range", i);
+  if (useful_flops) *useful_flops = bg::g_recs[i].useful_flops;
+  return BG_OK;
+}
+
+double bg_conv2d_useful_flops(int B, int H, int W, int Cin, int Cout, int ksize, int stride) {
+  if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || ksize < 1 || stride < 1) return 0.0;
+  return bg::conv_useful_flops(B, H, W, Cin, Cout, ksize, stride);
 }
 
 }  // extern "C"

@@ -6,6 +6,7 @@ network is SUM all-reduced once per optimiser step (losses are already written f
 wgan.py:130,157)."""
 from __future__ import annotations
 
+import datetime as _dt
 import os
 
 import torch
@@ -67,13 +68,29 @@ def init_from_env(backend=None):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     # BGAN_DIST_BACKEND=gloo: rehearsal of the multi-rank path where RCCL cannot run (several ranks on one card)
     backend = backend or os.environ.get("BGAN_DIST_BACKEND") or ("nccl" if use_cuda else "gloo")
+    # The rendezvous store comes FIRST and the device check runs on it BEFORE the process group exists: with device_id= the RCCL
+    # communicator is created inside init_process_group, so two ranks that ended up on one card would hang in there and a check
+    # placed after it would never run.  torch.distributed.rendezvous is the public env:// handler (it knows whether
+    # torchrun's agent already hosts the store); the same store is then handed to init_process_group.
+    rank = int(os.environ.get("RANK", "0"))
+    store = None
+    try:
+        store, rank, ws = next(iter(td.rendezvous("env://", rank, ws)))
+        store.set_timeout(_dt.timedelta(seconds=int(os.environ.get("BGAN_DIST_TIMEOUT_S", "600"))))
+    except Exception:                   # an exotic launcher: fall back to init's own rendezvous, check afterwards
+        store = None
+    if store is not None:
+        _check_one_device_per_rank(backend, store, rank, ws)
     kw = {}
     if use_cuda and backend == "nccl":
         # bind the communicator to this rank's card up front: no "guessing device ID based on global rank" (and no hang when
         # the rank -> GPU mapping is not the identity)
         kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
-    td.init_process_group(backend=backend, **kw)
-    _check_one_device_per_rank(backend)
+    if store is not None:
+        td.init_process_group(backend=backend, store=store, rank=rank, world_size=ws, **kw)
+    else:
+        td.init_process_group(backend=backend, **kw)
+        _check_one_device_per_rank(backend)
     return world_size()
 
 
@@ -105,17 +122,35 @@ def _distinct_devices(ids):
         seen[ident] = r
 
 
-def _check_one_device_per_rank(backend):
-    """After set_device and BEFORE the first collective: every rank publishes (host, card) through the rendezvous store (TCP,
+def _check_one_device_per_rank(backend, store=None, me=None, n=None):
+    """After set_device and BEFORE the communicator exists: every rank publishes (host, card) through the rendezvous store (TCP,
     no GPU involved) and reads everybody else's.  A per-rank mask and a box-wide mask look the same to local_rank(); this is
     where the second case -- two ranks silently on one card -- turns into an error instead of a hang."""
     if backend != "nccl" and os.environ.get("BGAN_DIST_CHECK_DEVICES") != "1":
         return
-    store = td.distributed_c10d._get_default_store()
-    me, n = td.get_rank(), td.get_world_size()
+    if os.environ.get("BGAN_DIST_CHECK_DEVICES") == "0":
+        return
+    if store is None:                   # fallback path only (no explicit store could be made): the group's own store
+        get = getattr(td.distributed_c10d, "_get_default_store", None)
+        if get is None:
+            return
+        store, me, n = get(), td.get_rank(), td.get_world_size()
     store.set(f"bgan_device_of_rank_{me}", _device_identity() or "?")
     ids = [store.get(f"bgan_device_of_rank_{r}").decode() for r in range(n)]
     ids = ["" if i == "?" else i for i in ids]
+    # Nobody may leave (and, raising, tear its end of the store down -- rank 0 usually HOSTS it) before everybody has read every
+    # identity: count the readers in, then let rank 0 wait for the others' acknowledgement; after its acknowledgement a rank does
+    # not touch the store again.
+    import time
+    store.add("bgan_device_check_read", 1)
+    t0 = time.time()
+    while store.add("bgan_device_check_read", 0) < n and time.time() - t0 < 120:
+        time.sleep(0.01)
+    if me != 0:
+        store.add("bgan_device_check_ack", 1)
+    else:
+        while store.add("bgan_device_check_ack", 0) < n - 1 and time.time() - t0 < 120:
+            time.sleep(0.01)
     _distinct_devices(ids)
 
 
@@ -142,13 +177,13 @@ class _RecordedWork:
     def wait(self):
         self._cur.wait()
         from . import program
-        if program._active is self._rec:
+        if program.active() is self._rec:
             self._rec.host_action(self._rewait)
 
 
 def _recorder():
     from . import program
-    return program._active
+    return program.active()
 
 
 def all_reduce_sum_async(flat):
@@ -363,6 +398,34 @@ def _quiesce_abi():
     before anything goes through torch's communicator, the C ABI's private stream is drained."""
     if AbiComm._inst is not None:
         AbiComm._inst.stream.synchronize()
+
+
+def evidence():
+    """What the collective layer itself says about the group, for a bench line: the backend, the number of
+    peers that TOOK PART in a collective (a SUM all-reduce of ones through the very communicator the gradients use -- not
+    WORLD_SIZE from the environment), every rank's physical device (uuid | PCI id, all-gathered), and, when the C ABI's
+    communicator is the route, ncclCommCount / ncclCommUserRank as RCCL reports them.  {} when no group was joined."""
+    if not is_initialized():
+        return {}
+    _quiesce_abi()
+    backend = td.get_backend()
+    on_gpu = backend == "nccl"
+    t = torch.ones(1, dtype=torch.float32, device="cuda" if on_gpu else "cpu")
+    td.all_reduce(t)
+    ident = _device_identity() if torch.cuda.is_available() else ""
+    ids = [None] * td.get_world_size()
+    td.all_gather_object(ids, ident)
+    out = {"backend": backend + (" (RCCL)" if on_gpu else ""), "world_size_env": int(os.environ.get("WORLD_SIZE", "1")),
+           "collective_nranks": int(round(float(t.item()))), "devices": ids,
+           "distinct_devices": len({i for i in ids if i}), "collective_route": os.environ.get("BGAN_DP_COLLECTIVE") or "torch"}
+    if on_gpu:
+        out["rccl_nranks"] = out["collective_nranks"]
+    if AbiComm._inst is not None:
+        import ctypes as C
+        n, r = C.c_int(), C.c_int()
+        AbiComm._inst._check(AbiComm._inst._lib.bg_comm_query(AbiComm._inst._h, C.byref(n), C.byref(r)), "bg_comm_query")
+        out["abi_comm"] = {"nranks": n.value, "rank": r.value}
+    return out
 
 
 def max_over_ranks(value: float) -> float:

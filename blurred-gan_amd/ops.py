@@ -47,8 +47,8 @@ def _ptr(t):
         _dev_index = cur
     if not t.is_contiguous():
         raise ValueError("tensor must be contiguous")
-    if program._active is not None:
-        program._active.keep.append(t)      # a step program holds this address: the tensor lives as long as the program
+    if program.active() is not None:
+        program.active().keep.append(t)      # a step program holds this address: the tensor lives as long as the program
     return t.data_ptr()                # a plain int (c_void_p parameter): one Python object less per operand and launch
 
 
@@ -408,8 +408,8 @@ def _draw_offset(out, offset, counter):
     obj, attr = counter
     inc = (out.numel() + 3) // 4
     offset = getattr(obj, attr)
-    if program._active is not None:
-        program._active.bind_rng(obj, attr, inc)        # the recorded launch re-reads the counter before every replay
+    if program.active() is not None:
+        program.active().bind_rng(obj, attr, inc)        # the recorded launch re-reads the counter before every replay
     setattr(obj, attr, offset + inc)
     return offset
 
@@ -462,9 +462,14 @@ def prof_reset():
     _lib.load().bg_prof_reset()
 
 
-def prof_records(with_exec=False):
+def conv2d_useful_flops(B, H, W, Cin, Cout, k=5, stride=2):
+    """Flops of a k x k SAME convolution that multiply real data (no zero-padding taps): bg_conv2d_useful_flops."""
+    return float(_lib.load().bg_conv2d_useful_flops(B, H, W, Cin, Cout, k, stride))
+
+
+def prof_records(with_exec=False, with_useful=False):
     """[(name, ms, algorithmic flops, algorithmic bytes)] per recorded launch; with_exec appends the flops the launch issued
-    on the matrix pipe (bg_prof_get_exec)."""
+    on the matrix pipe (bg_prof_get_exec), with_useful the flops that multiply real data (bg_prof_get_useful)."""
     lib = _lib.load()
     n = lib.bg_prof_count()
     out = []
@@ -475,6 +480,9 @@ def prof_records(with_exec=False):
         rec = (name.value.decode(), ms.value, fl.value, by.value)
         if with_exec:
             check(lib.bg_prof_get_exec(i, C.byref(ex)), "bg_prof_get_exec")
+            rec = rec + (ex.value,)
+        if with_useful:
+            check(lib.bg_prof_get_useful(i, C.byref(ex)), "bg_prof_get_useful")
             rec = rec + (ex.value,)
         out.append(rec)
     return out

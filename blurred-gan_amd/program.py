@@ -17,16 +17,34 @@ from __future__ import annotations
 import ctypes as C
 import math
 import os
+import threading
+import warnings
 from collections import OrderedDict
 
 from . import _lib
 
 N_SLOTS = 64
-_active = None              # the Recorder the current thread records into (ops / dist / wgan consult it)
+
+
+class _ThreadState(threading.local):
+    """The Recorder the CURRENT THREAD records into (ops / dist / wgan consult it).  Per thread, like the library's own recorder
+    state (csrc/program.hip: thread_local): a prefetch or metric thread that issues library calls while another thread records
+    neither lands in that program's keep list nor announces binds to a recorder that is not its own, and two models may record in
+    two threads at once."""
+    rec = None
+
+
+_tls = _ThreadState()
 
 
 def active():
-    return _active
+    return _tls.rec
+
+
+def __getattr__(name):                 # program._active: the historical spelling, read-only
+    if name == "_active":
+        return _tls.rec
+    raise AttributeError(name)
 
 
 def enabled_by_env():
@@ -67,20 +85,23 @@ class Recorder:
 
     # ---- while recording
     def __enter__(self):
-        global _active
-        assert _active is None, "a step program is already being recorded"
+        assert _tls.rec is None, "this thread is already recording a step program"
         _lib.check(self.lib.bg_program_record_begin(self.h), "bg_program_record_begin")
-        _active = self
+        _tls.rec = self
         return self
 
     def __exit__(self, et, ev, tb):
-        global _active
-        _active = None
+        _tls.rec = None
         rc = self.lib.bg_program_record_end(self.h)
         if et is None:
             _lib.check(rc, "bg_program_record_end")
             self.n_nodes = self.lib.bg_program_size(self.h)
             self.n_launches = self.lib.bg_program_launches(self.h)
+            # every announced slot must have become a binding of a launch argument: a dropped one would replay the recording
+            # step's lr_t / Philox offset for ever (same noise and masks every step) without any error
+            nb = self.lib.bg_program_binds(self.h)
+            if nb != self.n_slots:
+                raise _lib.BgError(f"step program: {self.n_slots} per-step values were announced but {nb} launch arguments were bound")
         return False
 
     def _slot(self):
@@ -152,8 +173,10 @@ class StepPrograms:
     def __init__(self, capacity=24):
         self.entries = OrderedDict()
         self.capacity = capacity
-        self.stats = {"eager": 0, "recorded": 0, "replayed": 0}
+        self.stats = {"eager": 0, "recorded": 0, "replayed": 0, "evicted": 0, "rerecorded": 0}
         self.last_was_replay = False
+        self._evicted = set()       # hashes of keys whose recorded program was dropped by the LRU rule
+        self._warned = False
 
     def clear(self):
         for e in self.entries.values():
@@ -169,6 +192,16 @@ class StepPrograms:
             self.stats["replayed"] += 1
             return e.replay(stream)
         if e is None:
+            if hash(key) in self._evicted:
+                # the working set of keys is larger than the cache: every return to an evicted key costs an eager step and a
+                # recording (e.g. persistent_input=True with a ring of more device buffers than `capacity` programs)
+                self.stats["rerecorded"] += 1
+                if not self._warned:
+                    self._warned = True
+                    warnings.warn(f"step programs: a key evicted from the cache of {self.capacity} programs is in use again -- the steps "
+                                  "cycle through more distinct (batch shape, input buffer, tap count, ...) combinations than the cache "
+                                  "holds and are re-recorded continuously; raise StepPrograms.capacity or feed fewer distinct input "
+                                  "buffers (persistent_input=True keys programs on the batch's device address)", RuntimeWarning, stacklevel=3)
             self.entries[key] = 0
             self.stats["eager"] += 1
             self._trim()
@@ -184,6 +217,8 @@ class StepPrograms:
 
     def _trim(self):
         while len(self.entries) > self.capacity:
-            _, e = self.entries.popitem(last=False)
+            k, e = self.entries.popitem(last=False)
             if isinstance(e, Recorder):
+                self.stats["evicted"] += 1
+                self._evicted.add(hash(k))
                 e.close()

@@ -7,6 +7,7 @@ Step order, training flags and loss algebra follow wgan.py:86-172, 234-285 inclu
 from __future__ import annotations
 
 import math
+import numbers
 import os
 from contextlib import contextmanager
 from dataclasses import dataclass
@@ -21,6 +22,26 @@ from .layers import Sequential, get_seed
 from .utils import JsonSerializable, ParseableFromCommandLine
 
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7       # tf.keras.optimizers.Adam defaults (wgan.py:56)
+
+
+_KEY_ENV = ("BGAN_NO_FUSED_BLUR3", "BGAN_NO_FOLD_MANY", "BGAN_NO_FUSED_BN_STATS", "BG_BLUR_NO_ROWS", "BG_BLUR_NO_PANEL", "BG_WGRAD_NO_STRIP")
+
+
+def _env_switches():
+    """Dispatch switches that the engine / the library read per call and that change a step's launch list: part of the step-program
+    key, so flipping one mid-run records a new program instead of replaying a stale launch list."""
+    return tuple(os.environ.get(k) for k in _KEY_ENV)
+
+
+def _plain(v):
+    """Hyper-parameter values as plain Python scalars (np.float32(1e-3) and 1e-3 must give the same program key)."""
+    if isinstance(v, (bool, np.bool_)):
+        return bool(v)
+    if isinstance(v, (numbers.Integral, np.integer)):
+        return int(v)
+    if isinstance(v, (numbers.Real, np.floating)):
+        return float(v)
+    return v
 
 
 @dataclass
@@ -62,8 +83,8 @@ class _Adam:
         self.iterations += 1
         t = self.iterations
         lr_t = float(self.learning_rate) * math.sqrt(1.0 - ADAM_B2 ** t) / (1.0 - ADAM_B1 ** t)
-        if program._active is not None:        # step program: the recorded launch takes lr_t of the NEXT iteration from a slot
-            program._active.bind_adam(self, ADAM_B1, ADAM_B2)
+        if program.active() is not None:        # step program: the recorded launch takes lr_t of the NEXT iteration from a slot
+            program.active().bind_adam(self, ADAM_B1, ADAM_B2)
         ops.adam(store.theta[:store.n_train], store.m[:store.n_train], store.v[:store.n_train],
                  store.grad[:store.n_train], lr_t, ADAM_B1, ADAM_B2, ADAM_EPS)
         store.tr_dirty = True
@@ -269,9 +290,15 @@ class WGAN:
         is part of the program key -- and no copy is made."""
         if self.persistent_input:
             return reals
-        st = self._reals_stage
-        if st is None or st.shape != reals.shape:
-            st = self._reals_stage = torch.empty_like(reals)
+        # one staging buffer PER BATCH SHAPE, kept for the life of the model: recorded programs hold its address, so a buffer that
+        # was re-allocated on every shape switch (the partial last batch of an epoch) would strand the programs of both shapes at
+        # each switch -- two eager steps and a recording per step kind, every epoch (ADVICE r4)
+        if self._reals_stage is None:
+            self._reals_stage = {}
+        key = (tuple(reals.shape), reals.dtype, reals.device)
+        st = self._reals_stage.get(key)
+        if st is None:
+            st = self._reals_stage[key] = torch.empty_like(reals)
         if st.data_ptr() != reals.data_ptr():
             st.copy_(reals, non_blocking=True)
         return st
@@ -279,10 +306,11 @@ class WGAN:
     def _step_key(self, kind, reals):
         """Everything that shapes the launch list of a step or is baked into its kernel arguments."""
         G, D = self.generator.net(), self.discriminator.net()
-        hp = tuple(sorted((k, v) for k, v in vars(self.hparams).items() if isinstance(v, (int, float, str, bool))))
+        hp = tuple(sorted((k, _plain(v)) for k, v in vars(self.hparams).items() if isinstance(v, (numbers.Number, np.generic, str, bool))))
         return (kind, tuple(reals.shape), reals.data_ptr(), D.blur_n_taps(), G.store.tr_dirty, D.store.tr_dirty, self.merge_critic_passes,
                 self.merge_gp_filter_gradients, self.sync_batchnorm, self.gp_zero_norm_guard, self.reproduce_vector_loss_quirk,
-                self.sync_metrics, dist.collectives_active(), dist.world_size(), G.fuse_bn_stats, D.fuse_bn_stats, hp)
+                self.sync_metrics, dist.collectives_active(), dist.world_size(), G.fuse_bn_stats, D.fuse_bn_stats,
+                G.store.n_train, D.store.n_train, G.bn_bwd_read_y, _env_switches(), hp)
 
     def _exit_state(self):
         G, D = self.generator.net(), self.discriminator.net()

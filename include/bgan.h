@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define BG_ABI_VERSION 4
+#define BG_ABI_VERSION 5
 
 typedef enum {
   BG_OK = 0,
@@ -53,6 +53,14 @@ int bg_prof_get(int i, char* name, int name_cap, float* ms, double* flops, doubl
 /* flops record i ISSUED on the matrix pipe: whole MFMA tiles (row / column padding counted), minus the padding taps the
    position-major tiles skip.  Equals the algorithmic figure of bg_prof_get for kernels that do not report their own. */
 int bg_prof_get_exec(int i, double* exec_flops);
+/* flops of record i that multiply REAL data: SURVEY 8d's F_l (bg_prof_get) charges all 25 taps at every output position of a
+   SAME convolution (demo_celeba.py:62,99); the taps that land on the zero padding -- 51 % of them on a 4x4 map, 28 % on 8x8 --
+   are work no implementation has to do.  "useful" counts exactly the (output pixel, tap) pairs inside the image, with no tile
+   padding either, so  useful <= executed-or-algorithmic  and a rate priced by it cannot read above the roof.  Equals the
+   algorithmic figure for launches that are not convolutions.  bg_conv2d_useful_flops is the closed form (conv input side
+   H x W x Cin; one count serves the forward, the data gradient / transposed convolution and the filter gradient). */
+int bg_prof_get_useful(int i, double* useful_flops);
+double bg_conv2d_useful_flops(int B, int H, int W, int Cin, int Cout, int ksize, int stride);
 
 /* Named ranges on the profiler timeline (rocprofv3 --marker-trace): D-step / G-step / blur / all-reduce of one train_on_batch
    (wgan.py:86-114).  roctx (librocprofiler-sdk-roctx.so) is bound with dlopen on first use; without it, or with
@@ -287,7 +295,13 @@ int bg_keep_mask_u8(uint8_t* out, size_t n, float keep_prob, uint64_t seed, uint
  * bg_dstep / bg_gstep replay a whole program: one call per discriminator_step / generator_step.
  * bg_program_graph_launch: the same node range as one hipGraph (kernel nodes in a linear chain, bound arguments refreshed with
  * hipGraphExecKernelNodeSetParams); with bg_prof_enable(1) it falls back to the node-by-node replay.
- * Profiling brackets travel with the program: a replay under bg_prof_enable(1) yields the same records as the eager step. */
+ * Profiling brackets travel with the program: a replay under bg_prof_enable(1) yields the same records as the eager step.
+ * Synchronisation: no call of this section waits for the device, with ONE exception -- destroying, evicting or re-recording a
+ * program that has been launched in graph form (bg_program_destroy, bg_program_record_begin) waits for the STREAM of its last
+ * bg_program_graph_launch (hipStreamSynchronize, never hipDeviceSynchronize) before the executable graphs are freed.  The
+ * node-by-node replay (the default) never synchronises.
+ * A binding that does not fit the launch it was announced for (wrong argument size, no launch at all) fails
+ * bg_program_record_end: a silently dropped one would replay the recording step's value for ever. */
 typedef struct bg_program bg_program;
 #define BG_BIND_ADAM_LR 1     /* bg_adam_f32: lr_t <- (float) slots_f64[slot]                         */
 #define BG_BIND_RNG_OFFSET 2  /* bg_uniform_f32, bg_keep_mask_u8: offset <- slots_u64[slot]            */
@@ -320,6 +334,9 @@ int bg_comm_init(bg_comm** out, int rank, int nranks, const unsigned char* id_by
  * SyncBN statistics exchanges in line on the compute stream): the calls are then ordered by RCCL in ISSUE order on the host, so
  * every rank must issue them in the same order (the step program guarantees it); a host that cannot should keep to one stream. */
 int bg_allreduce_sum_f32(bg_comm* comm, float* buf_d, size_t n, void* stream);
+/* ranks and own rank as the communicator itself reports them (ncclCommCount / ncclCommUserRank): evidence for a bench line
+   that the collective really ran over N peers (bench.py --gpus N "rccl_nranks"). */
+int bg_comm_query(bg_comm* comm, int* nranks, int* rank);
 int bg_comm_destroy(bg_comm* comm);
 
 #ifdef __cplusplus

@@ -31,7 +31,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
         assert hasattr(lib, name), f"libbgan_hip.so does not export {name}"
         assert name in _lib.SIGNATURES, f"_lib.py does not bind {name}"
     assert set(_lib.SIGNATURES) <= declared
-    assert lib.bg_version() == 4          # 2: bg_epilogue grew the BatchNorm statistics fields; 3: stats_rows returned through the epilogue; 4: step programs (bg_program_*, bg_dstep, bg_gstep), bg_copy_f32
+    assert lib.bg_version() == 5          # 2: bg_epilogue grew the BatchNorm statistics fields; 3: stats_rows returned through the epilogue; 4: step programs (bg_program_*, bg_dstep, bg_gstep), bg_copy_f32; 5: bg_prof_get_useful, bg_conv2d_useful_flops, bg_comm_query
 
 
 def test_host_blur_policy_and_taps_match_oracle(lib):

@@ -157,6 +157,76 @@ def test_step_program_api_without_a_gpu():
     calls = []
     for _ in range(3):
         progs.run("k", lambda: calls.append(1) or "x", None)
-    assert calls == [1, 1] and progs.stats == {"eager": 1, "recorded": 1, "replayed": 1} and progs.last_was_replay
+    assert calls == [1, 1] and progs.stats == {"eager": 1, "recorded": 1, "replayed": 1, "evicted": 0, "rerecorded": 0} and progs.last_was_replay
     progs.run("k2", lambda: None, None); progs.run("k3", lambda: None, None)
     assert list(progs.entries) == ["k2", "k3"]                                 # least recently used program dropped
+
+
+def test_recorder_state_is_per_thread_like_the_library():
+    """program.py's recording state was process-global while csrc/program.hip's is thread_local: a library call from
+    a second thread during a recording step landed in the wrong recorder.  Two threads now record two programs at once, and a
+    thread that is not recording sees no active recorder."""
+    import threading
+    from blurred_gan_amd import program
+    seen, errs = {}, []
+    gate = threading.Barrier(2, timeout=30)
+
+    def worker(name):
+        try:
+            rec = program.Recorder()
+            with rec:
+                gate.wait()                               # both threads are inside their recording at the same time
+                seen[name] = program.active() is rec and program._active is rec
+                gate.wait()
+            seen[name] = seen[name] and program.active() is None
+            rec.close()
+        except Exception as e:                            # noqa: BLE001
+            errs.append(repr(e))
+
+    ts = [threading.Thread(target=worker, args=(n,)) for n in ("a", "b")]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join(60)
+    assert not errs, errs
+    assert seen == {"a": True, "b": True}
+    assert program.active() is None                       # the main thread never recorded
+
+
+def test_step_programs_warn_when_an_evicted_key_comes_back():
+    """StepPrograms is an LRU of `capacity` programs keyed (among others) on the batch's device address; a loader
+    cycling through more buffers than that re-records for ever.  That now shows: a warning and a 'rerecorded' count."""
+    import warnings
+    from blurred_gan_amd import program
+    sp = program.StepPrograms(capacity=2)
+    calls = []
+    for rnd in range(3):
+        for key in ("k0", "k1", "k2"):                    # three keys through a cache of two
+            with warnings.catch_warnings(record=True) as w:
+                warnings.simplefilter("always")
+                sp.run(key, lambda: calls.append(key), None)
+                if rnd == 0:
+                    assert not w
+    # round 0: three eager runs (k0 evicted as a placeholder, never recorded); nothing was RECORDED and evicted yet
+    assert sp.stats["evicted"] == 0 and sp.stats["rerecorded"] == 0
+    # now with real recordings: capacity 1, two keys alternating -> every return to a key finds its program evicted
+    sp = program.StepPrograms(capacity=1)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        for _ in range(3):
+            for key in ("a", "b"):
+                sp.run(key, lambda: None, None)           # eager
+                sp.run(key, lambda: None, None)           # recorded (an empty program)
+    assert sp.stats["evicted"] >= 4 and sp.stats["rerecorded"] >= 4, sp.stats
+    assert sum("re-recorded continuously" in str(x.message) for x in w) == 1      # warned once, not per step
+    sp.clear()
+
+
+def test_step_key_normalises_numpy_hyperparameters():
+    """np.float32 hyper-parameters fell through the isinstance filter of the step-program key."""
+    import numpy as np
+    from blurred_gan_amd import wgan
+    assert wgan._plain(np.float32(0.5)) == 0.5 and type(wgan._plain(np.float32(0.5))) is float
+    assert wgan._plain(np.int64(3)) == 3 and type(wgan._plain(np.int64(3))) is int
+    assert wgan._plain(True) is True and wgan._plain("adam") == "adam"
+    assert len(wgan._env_switches()) == len(wgan._KEY_ENV)

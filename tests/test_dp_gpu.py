@@ -263,6 +263,37 @@ def test_bench_two_ranks_strong_scaling_smoke():
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["scaling"] == "strong" and out["config"]["global_batch"] == 16 and out["value"] > 0
     assert out["config"]["parallelism"] == "dp2" and "8/GPU" in out["config"]["workload"]
+    # the collective layer's own account of the group: two peers counted by an all-reduce through the step's
+    # communicator; both ranks rehearse on the box's one card, and the line says so
+    dp = out["dp"]
+    assert dp["backend"] == "gloo" and dp["collective_nranks"] == 2 and dp["world_size_env"] == 2 and len(dp["devices"]) == 2
+    assert dp["distinct_devices"] == 1 and dp["devices"][0] == dp["devices"][1] and dp["devices"][0]
+    assert "rccl_nranks" not in dp                         # only an RCCL group may claim RCCL peers
+
+
+def test_bench_one_rank_rccl_line_carries_the_communicators_own_count():
+    """bench.py --gpus 1 with every collective forced through RCCL (BGAN_DP_FORCE_COLLECTIVES=1, the N = 1 point of the scaling
+    run that can be cross-checked with the plain bench line): backend nccl, rccl_nranks 1 from an all-reduce, the card's uuid;
+    through the C ABI's communicator also ncclCommCount / ncclCommUserRank (bg_comm_query)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for route in ("torch", "abi"):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = dict(os.environ, BGAN_DP_FORCE_COLLECTIVES="1", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", BGAN_DP_COLLECTIVE=route)
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--arch", "mnist", "--batch", "16",
+                            "--steps", "3", "--warmup", "3", "--no-cpu-baseline", "--no-profile"], env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+        dp = out["dp"]
+        assert dp["backend"].startswith("nccl") and dp["rccl_nranks"] == 1 and dp["collective_route"] == route and dp["devices"][0]
+        if route == "abi":
+            assert dp["abi_comm"] == {"nranks": 1, "rank": 0}
 
 
 def _replay_worker(rank, world, port, out_dir, backend, replay, tag):

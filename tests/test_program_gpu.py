@@ -153,3 +153,22 @@ def test_graph_replay_of_a_whole_step_equals_eager(tmp_path, monkeypatch):
         assert a.train_on_batch(reals) == b.train_on_batch(reals)
         _same_state(a, b)
     assert b._programs.stats["replayed"] >= 6
+
+
+def test_alternating_batch_shapes_keep_their_programs(tmp_path):
+    """the partial last batch of an epoch has another shape; the staging buffer used to be re-allocated at every switch,
+    which stranded the recorded programs of BOTH shapes (their key holds the buffer's address).  One staging buffer per shape:
+    after the first epoch nothing is recorded again, and the steps still equal the eager path's bit for bit."""
+    eager = _make("tiny", 4, 5, tmp_path, False, 0.9)
+    prog = _make("tiny", 4, 5, tmp_path, True, 0.9)
+    g = torch.Generator().manual_seed(11)
+    recorded = []
+    for epoch in range(4):
+        for B in (4, 4, 4, 4, 3, 3, 3):                 # full batches, then "partial" ones (three each so that both shapes get to replay)
+            reals = (torch.rand(B, *SHAPES["tiny"], generator=g) * 2 - 1).cuda()
+            assert eager.train_on_batch(reals) == prog.train_on_batch(reals.clone())
+        recorded.append(prog._programs.stats["recorded"])
+    _same_state(eager, prog)
+    assert recorded[0] == 4, recorded                     # D and G programs of two shapes
+    assert recorded[1:] == [recorded[0]] * 3, recorded    # ... and never again
+    assert prog._programs.stats["rerecorded"] == 0 and len(prog._reals_stage) == 2

@@ -205,14 +205,13 @@ def test_gradients_match_oracle_on_the_same_relu_branches(arch, B, std, steps, s
           f"critic {worst['d'][0]:.1e} / {worst['d'][1]:.0e}")
 
 
-def test_celeba64_batch256_step_matches_oracle():
-    """The exact BASELINE.json configuration (64x64, batch 256, sigma 5 -> 31 taps): one full train_on_batch against the
+def _full_batch_step_matches_oracle(arch, B, std):
+    """One BASELINE.json configuration at its REAL batch: one full train_on_batch against the
     float64 numpy oracle on identical injected randomness (learning rate 0 so the gradients can be read back), the oracle
     differentiating on the LeakyReLU branches the product took (48 M critic units and 67 M generator units per step: a few dozen
     sit within float32 rounding of the kink, and each one that lands on the other branch moves a bias-gradient element -- a sum
     of 131 k terms of both signs -- by up to 0.5 %; see test_gradients_match_oracle_on_the_same_relu_branches).  The oracle
     needs about half a minute of host time at this batch."""
-    arch, B, std = "celeba64", 256, 5.0
     gan, st, reals, rng = _make(arch, B, std, seed=9)
     rnd = S.draw_randomness(arch, B, rng, np.float64)
     hp = dict(S.DEFAULT_HP, global_batch_size=B)
@@ -233,7 +232,7 @@ def test_celeba64_batch256_step_matches_oracle():
                 l2, c = rel_l2(a, b), 1.0 - cosine(a, b)
                 worst[key] = (max(worst.get(key, (0, 0))[0], l2), max(worst.get(key, (0, 0))[1], c))
                 assert l2 <= 2e-5 and c <= 1e-9, (key, i, a.shape, l2, c)          # measured: generator 3.2e-6, critic 3.7e-6
-    print(f"[same branches] celeba64 B=256: worst rel-L2 / (1-cos): generator {worst['g'][0]:.1e} / {worst['g'][1]:.0e}, "
+    print(f"[same branches] {arch} B={B}: worst rel-L2 / (1-cos): generator {worst['g'][0]:.1e} / {worst['g'][1]:.0e}, "
           f"critic {worst['d'][0]:.1e} / {worst['d'][1]:.0e}")
     np.testing.assert_allclose(gan.images[0].cpu().numpy(), fakes, rtol=1e-4, atol=1e-5)
     for k in ("real_scores", "disc_loss", "gp_term", "norm_term"):
@@ -284,7 +283,7 @@ def test_celeba64_batch256_step_matches_oracle():
                     d_budget += k * (25 * conv_cin[li] + 1)
         flips[name] = n_flip
     total = sum(flips.values())
-    print(f"[own branches] celeba64 B=256: {total} of {units} LeakyReLU units on another branch than the float64 oracle {flips}; "
+    print(f"[own branches] {arch} B={B}: {total} of {units} LeakyReLU units on another branch than the float64 oracle {flips}; "
           f"largest |pre-activation| among them {worst_margin:.1e} of its layer's rms")
     assert total <= 400, flips                            # measured: 36 (generator 30, critic 6)
     assert worst_margin <= 5e-5, worst_margin             # every one of them within float32 rounding of the kink (measured 6.3e-6 of the layer rms)
@@ -305,6 +304,20 @@ def test_celeba64_batch256_step_matches_oracle():
           f"flipped critic units can touch: {d_budget}); generator worst rel-L2 {worst_g:.1e}")
     assert outside <= d_budget, (outside, d_budget)
     assert worst_g <= 2e-2, worst_g                        # BatchNorm's backward spreads one flipped unit over its whole channel
+
+
+
+def test_celeba64_batch256_step_matches_oracle():
+    """BASELINE.json configs[1], the headline: 64x64 (build-defined 64-arch), batch 256, sigma 5 -> 31 taps."""
+    _full_batch_step_matches_oracle("celeba64", 256, 5.0)
+
+
+def test_celeba128_batch128_step_matches_oracle():
+    """BASELINE.json configs[3] (C4) at ITS batch: the verbatim 128-pixel stacks of demo_celeba.py:51-124, batch 128, sigma 5 ->
+    31 taps, wgan.py:132-172,234-285.  At batch 128 the dispatcher picks other tiles, split-K plans, position-major orders and
+    strip counts than at the batch 2-4 of the other celeba128 cases, and the 16-channel kernels' persistent strips run at their
+    real occupancy: this is the one BASELINE configuration whose product dispatch had never met the oracle."""
+    _full_batch_step_matches_oracle("celeba128", 128, 5.0)
 
 
 def test_gradient_penalty_value_function():

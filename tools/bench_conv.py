@@ -34,16 +34,17 @@ def run(fn, iters):
     for _ in range(iters):
         fn()
     torch.cuda.synchronize()
-    recs = ops.prof_records()
+    recs = ops.prof_records(with_useful=True)
     ops.prof_enable(False)
     ops.prof_reset()
     ms = sum(r[1] for r in recs) / iters
     fl = sum(r[2] for r in recs) / iters
+    us = sum(r[4] for r in recs) / iters
     per = {}
     for r in recs:
         per[r[0]] = per.get(r[0], 0.0) + r[1] / iters
     names = [f"{k}={v * 1e3:.1f}us" for k, v in sorted(per.items())]
-    return ms, fl, names
+    return ms, fl, us, names
 
 
 def main():
@@ -56,7 +57,9 @@ def main():
     a = ap.parse_args()
     B = a.batch
     torch.manual_seed(0)
-    print(f"{'layer':<20}{'op':<8}{'ms':>9}{'TFLOP/s':>10}{'%peak':>8}  kernels")
+    # %peak: SURVEY 8d's count (every tap at every output position); %useful: only the taps that meet real data (bg_prof_get_useful) --
+    # the column that cannot exceed 100 (on 4x4 maps 51 % of the 25 taps land on the SAME zero padding and are skipped, not multiplied)
+    print(f"{'layer':<20}{'op':<8}{'ms':>9}{'TFLOP/s':>10}{'%peak':>8}{'%useful':>9}  kernels")
     tot = {}
     for name, H, W, Ci, Co, s in LAYERS[a.arch]:
         if a.only and not any(o in name for o in a.only.split(",")):
@@ -81,14 +84,15 @@ def main():
             ed = ops.epilogue(ops.EPI_MUL_GRAD, ref=ref_x, keep=keep_x, scale=1 / 0.7, ws=wsk if nd else None)
         for op, fn in (("fwd", lambda: ops.conv2d_fwd(x, wT, y, 5, s, ef)), ("dgrad", lambda: ops.conv2d_bwd_data(dy, w, dx, 5, s, ed)),
                        ("wgrad", lambda: ops.conv2d_bwd_filter(x, dy, dw, 5, s, 0.0, 1.0, ws))):
-            ms, fl, names = run(fn, a.iters)
+            ms, fl, us, names = run(fn, a.iters)
             tf = fl / (ms * 1e-3) / 1e12
-            tot.setdefault(op, [0.0, 0.0])
+            tot.setdefault(op, [0.0, 0.0, 0.0])
             tot[op][0] += ms
             tot[op][1] += fl
-            print(f"{name:<20}{op:<8}{ms:9.4f}{tf:10.2f}{100 * tf / 157.3:8.1f}  {','.join(names)}")
-    for op, (ms, fl) in tot.items():
-        print(f"{'TOTAL':<20}{op:<8}{ms:9.4f}{fl / (ms * 1e-3) / 1e12:10.2f}{100 * fl / (ms * 1e-3) / 1e12 / 157.3:8.1f}")
+            tot[op][2] += us
+            print(f"{name:<20}{op:<8}{ms:9.4f}{tf:10.2f}{100 * tf / 157.3:8.1f}{100 * us / (ms * 1e-3) / 1e12 / 157.3:9.1f}  {','.join(names)}")
+    for op, (ms, fl, us) in tot.items():
+        print(f"{'TOTAL':<20}{op:<8}{ms:9.4f}{fl / (ms * 1e-3) / 1e12:10.2f}{100 * fl / (ms * 1e-3) / 1e12 / 157.3:8.1f}{100 * us / (ms * 1e-3) / 1e12 / 157.3:9.1f}")
 
 
 if __name__ == "__main__":
