@@ -20,6 +20,32 @@
 namespace bg {
 }
 
+#if defined(BG_DIAG) && defined(IGEMM_CLOCK)
+// diagnostic build (tools/igemm_clock.py): every workgroup leaves the shader ticks (s_memtime) of its K loop, the 100 MHz times
+// (s_memrealtime) of its entry, loop start and loop end, and where it ran (HW_ID, XCC_ID).  ticks / loop time x 100 MHz is the
+// shader clock the kernel really ran at (cdna_hip_programming.md section 7, in-kernel stamps).
+__device__ unsigned long long bg_diag_clock[4 * 8192];
+__device__ unsigned bg_diag_hw[2 * 8192];
+// raw records of the last launch: out[6 i ..] = shader ticks, entry, loop start, loop end, HW_ID, XCC_ID; clears the table
+extern "C" int bg_diag_clock_dump(unsigned long long* out, int n_wg) {
+  static unsigned long long h[4 * 8192];
+  static unsigned hw[2 * 8192];
+  if (hipMemcpyFromSymbol(h, HIP_SYMBOL(bg_diag_clock), sizeof h) != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(hw, HIP_SYMBOL(bg_diag_hw), sizeof hw) != hipSuccess) return -1;
+  int n = 0;
+  for (int i = 0; i < 8192 && i < n_wg; ++i) {
+    if (!h[4 * i + 3]) continue;
+    for (int k = 0; k < 4; ++k) out[6 * n + k] = h[4 * i + k];
+    out[6 * n + 4] = hw[2 * i];
+    out[6 * n + 5] = hw[2 * i + 1];
+    ++n;
+  }
+  for (int i = 0; i < 4 * 8192; ++i) h[i] = 0;
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(bg_diag_clock), h, sizeof h);
+  return n;
+}
+#endif
+
 namespace {
 
 using bg::GatherParams;
@@ -63,6 +89,9 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
   constexpr bool TR = !STATS;
   __shared__ __attribute__((aligned(16))) float s_epi[2][BN];      // TR: bias and folded-BatchNorm scale of the tile's columns
 
+#if defined(BG_DIAG) && defined(IGEMM_CLOCK)
+  const unsigned long long dg_re = __builtin_amdgcn_s_memrealtime();
+#endif
   // A workgroup owns one output tile of `pm` sub-pixel phases (same anchors, different tap sets and destination offsets).
   // pm = 2 pairs the 9-tap with the 4-tap phase and the two 6-tap phases.
   const int pm = p.pmerge, ngroups = p.nphase / pm;
@@ -409,13 +438,46 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
     } while (c_left == 0);
   };
   if (c_left == 0) phase_done();
+#if defined(BG_DIAG) && defined(IGEMM_CLOCK)
+  const unsigned long long dg_t0 = __builtin_amdgcn_s_memtime(), dg_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   const int nsteps2 = (nsteps + 1) & ~1;                       // steps come in (even, odd) pairs; a padded step adds zeros
+#if defined(IGEMM_PRIO_ROT) || defined(IGEMM_PRIO_INV)
+  // experiment (profiles/r05_a_gather_gemm_limits.md): the four workgroups of a CU do not share its matrix pipes evenly -- they end
+  // one after the other, and the CU's last quarter runs with one to three of them.  Wave priority by residency slot, fixed
+  // (youngest first) or rotating every eight steps.
+  const int prio_slot = (int)((((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) >> 8) & 3u);
+#endif
+#if defined(IGEMM_PRIO_INV)
+  switch (prio_slot) { case 0: __builtin_amdgcn_s_setprio(0); break; case 1: __builtin_amdgcn_s_setprio(1); break; case 2: __builtin_amdgcn_s_setprio(2); break; default: __builtin_amdgcn_s_setprio(3); break; }
+#endif
   for (int step = 0; step < nsteps2; step += 2) {
+#if defined(IGEMM_PRIO_ROT)
+    if ((step & 7) == 0) {
+      switch (((step >> 3) + prio_slot) & 3) {
+        case 0: __builtin_amdgcn_s_setprio(0); break;
+        case 1: __builtin_amdgcn_s_setprio(1); break;
+        case 2: __builtin_amdgcn_s_setprio(2); break;
+        default: __builtin_amdgcn_s_setprio(3); break;
+      }
+    }
+#endif
     step_body(0, [&]() { lstore(1, regA1, regB1); gload(regA1, regB1); });
     if (--c_left == 0) phase_done();
     step_body(1, [&]() { lstore(0, regA0, regB0); gload(regA0, regB0); });
     if (--c_left == 0) phase_done();
   }
+#if defined(BG_DIAG) && defined(IGEMM_CLOCK)
+  {
+    const unsigned long long dg_t1 = __builtin_amdgcn_s_memtime(), dg_r1 = __builtin_amdgcn_s_memrealtime();
+    const unsigned w = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    if (tid == 0 && w < 8192) {
+      bg_diag_clock[4 * w] = dg_t1 - dg_t0; bg_diag_clock[4 * w + 1] = dg_re; bg_diag_clock[4 * w + 2] = dg_r0; bg_diag_clock[4 * w + 3] = dg_r1;
+      bg_diag_hw[2 * w] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));
+      bg_diag_hw[2 * w + 1] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11));
+    }
+  }
+#endif
   if (do_stats) {
     // lane halves hold different rows of the same column; waves along M share columns: fixed-order sums through LDS
     __syncthreads();
