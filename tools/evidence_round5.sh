@@ -1,6 +1,6 @@
 #!/bin/bash
-# Round-4 evidence on the GPU box, everything into a fresh gpurun_out/<tag>/evidence_round4/ (run through gpurun, ~6 minutes):
-#   tools/evidence_round4.sh <r04_stage>
+# Round-5 evidence on the GPU box, everything into a fresh gpurun_out/<tag>/evidence_round5/ (run through gpurun, ~6 minutes):
+#   tools/evidence_round5.sh <r04_stage>
 # PMC traffic of the C2 and C4 steps (+ the per-launch filter-gradient table), the matrix-pipe counters of both, the step bench
 # lines (after traffic_update, so that roofline.traffic is filled in), kernel-trace timelines of the MNIST step (replay / eager),
 # host time per step (eager / replay / graph), the one-rank collective rehearsals.
@@ -8,7 +8,7 @@ set -e
 cd ${GRAFT_REPO_ROOT:-$(pwd)}
 . tools/_fresh.sh "$@"
 export OUT
-for c in "c2 celeba64 256" "c4 celeba128 128"; do set -- $c
+for c in "c2 celeba64 256" "c4 celeba128 128" "c1 mnist 64"; do set -- $c
   tools/pmc_step.sh $1 --arch $2 > $OUT/pmc_$1.log 2>&1 || { tail -5 $OUT/pmc_$1.log; exit 1; }
   python3 tools/traffic_update.py $2 $3 $OUT/pmc_$1_traffic.json
   cp $OUT/pmc_$1.md $OUT/${tag}_pmc_traffic_$1.md; cp $OUT/pmc_$1_traffic.json.wgrad.md $OUT/${tag}_pmc_wgrad_launches_$1.md

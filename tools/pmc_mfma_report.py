@@ -2,9 +2,13 @@
 """Per-kernel matrix-pipe utilisation out of one rocprofv3 --pmc pass (tools/pmc_mfma.sh):
   MFMA busy      = SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES): share of the CU-busy time in which a SIMD's matrix pipe works
                    (4 SIMDs per CU; 1.0 = every SIMD of every busy CU issues MFMAs back to back)
-  clock          = GRBM_GUI_ACTIVE / 8 / duration (the counter is the sum over the 8 XCDs; MI355X_MICROARCH.md, DVFS: reads high
-                   on dispatches shorter than ~0.3 ms)
-  of peak        = MFMA busy x clock / 2.4 GHz: the fraction of the datasheet matrix rate the pipe delivered in that kernel.
+  GUI-active GHz = GRBM_GUI_ACTIVE / 8 / duration (the counter is the sum over the 8 XCDs).  NOT the shader clock: the GUI is active
+                   before and after the waves run, so the ratio reads 3-7 "GHz" on kernels of a few microseconds (round-4 verdict) and
+                   2.41 on every long one, while in-kernel stamps (s_memtime / s_memrealtime, tools/igemm_clock.py,
+                   profiles/r05_a_gather_gemm_limits.md) put the same gather-GEMM launches at 1.9-2.37 GHz.  It is printed for
+                   kernels of >= 30 us only, as an upper bound.
+  of peak        = MFMA busy x min(GUI-active GHz, 2.4) / 2.4 GHz, kernels of >= 30 us only: an UPPER bound on the fraction of the
+                   datasheet matrix rate the pipe delivered (the busy share itself does not depend on the clock).
 Usage: pmc_mfma_report.py <dir> <out.md> [title]"""
 import csv
 import glob
@@ -45,13 +49,16 @@ def main():
     with open(out, "w") as fh:
         fh.write(f"# {title}\n\nsource: `{os.path.relpath(cf[0])}` (`rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE "
                  f"--kernel-trace`), last two thirds of the dispatches; durations from the same pass's kernel trace\n\n"
-                 "| kernel | launches | total ms | avg us | MFMA busy / (4 x CU busy) | clock GHz | of the 2.4 GHz matrix peak |\n|---|---|---|---|---|---|---|\n")
+                 "| kernel | launches | total ms | avg us | MFMA busy / (4 x CU busy) | GUI-active GHz (>= 30 us kernels; upper bound of the clock) | of the 2.4 GHz matrix peak (upper bound) |\n|---|---|---|---|---|---|---|\n")
         for name, (n, t, mf, cu, gui) in rows:
             if t / total < 0.002:
                 continue
             busy = mf / (4.0 * cu) if cu else 0.0
             clk = gui / 8.0 / t / 1e9 if t else 0.0
-            fh.write(f"| `{name[:100]}` | {n} | {t * 1e3:.3f} | {t / n * 1e6:.1f} | {busy:.3f} | {clk:.2f} | {busy * clk / 2.4:.3f} |\n")
+            if t / n >= 30e-6:
+                fh.write(f"| `{name[:100]}` | {n} | {t * 1e3:.3f} | {t / n * 1e6:.1f} | {busy:.3f} | {clk:.2f} | {busy * min(clk, 2.4) / 2.4:.3f} |\n")
+            else:                                               # GUI-active over the duration says nothing about a kernel this short
+                fh.write(f"| `{name[:100]}` | {n} | {t * 1e3:.3f} | {t / n * 1e6:.1f} | {busy:.3f} | - | - |\n")
     print(open(out).read())
 
 
