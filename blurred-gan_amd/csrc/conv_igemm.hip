@@ -61,7 +61,10 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 // one: the two running sums per accumulator column cost the 64x64 tile its fourth wave per SIMD (103 -> 119 + 16 registers),
 // and the plain variant is the dominant kernel of the step.
 template <int BM, int BN, int BK, int WAVES_M, int WAVES_N, bool STATS = false>
-__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !STATS) ? 4 : 1) void conv_igemm_kernel(const GatherParams p) {
+#ifndef IGEMM_BK16_WAVES
+#define IGEMM_BK16_WAVES 4
+#endif
+__global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !STATS) ? (BK == 16 ? IGEMM_BK16_WAVES : 4) : 1) void conv_igemm_kernel(const GatherParams p) {
   constexpr int NT = WAVES_M * WAVES_N * 64;     // 4 or 8 waves per workgroup
   static_assert(NT == 256 || NT == 512, "4 or 8 waves per workgroup");
   static_assert(BK == 16 || BK == 32, "BK");
