@@ -943,6 +943,7 @@ __global__ __launch_bounds__(256) void transpose_batched_kernel(const float* __r
 // ------------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------------
+
 int max_phase_m(const GatherParams& p) {
   int mx = 0;
   for (int i = 0; i < p.nphase; ++i) mx = std::max(mx, p.B * p.ph[i].Ha * p.ph[i].Wa);
