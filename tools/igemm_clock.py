@@ -65,7 +65,7 @@ def main():
             ghz = float(r[:, 0].sum() / (r[:, 3] - r[:, 2]).sum() * 0.1)
             tf = fl / (us * 1e-6) / 1e12
             xcc = r[:, 5] & 15
-            cu = xcc * 64 + ((r[:, 4] >> 13) & 7) * 8 + ((r[:, 4] >> 12) & 1) * 4 * 0 + ((r[:, 4] >> 8) & 15)
+            cu = xcc * 128 + ((r[:, 4] >> 13) & 7) * 32 + ((r[:, 4] >> 12) & 1) * 16 + ((r[:, 4] >> 8) & 15)      # HW_ID: se_id [15:13], sh_id [12], cu_id [11:8]
             cus = np.unique(cu)
             last = np.array([end[cu == c].max() for c in cus])
             first = np.array([end[cu == c].min() for c in cus])
