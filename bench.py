@@ -238,6 +238,7 @@ def bench_blur(args):
     dist.barrier()
     torch.cuda.synchronize()
     dt = dist.max_over_ranks(time.perf_counter() - t0)
+    dp_evidence = dist.evidence()
     alg_bytes = 8.0 * B * H * W * C                              # per application
     value = alg_bytes * apps * args.steps * world / dt / 1e9
     ops.prof_reset()
@@ -281,6 +282,8 @@ def bench_blur(args):
                "config": {"workload": f"blur256: {B}x{H}x{W}x{C} per GPU, sigma {args.sigma} ({nt} taps), {apps} blur applications per step",
                           "global_batch": B * world, "parallelism": f"dp{world}"},
                "roofline": roof}
+        if dp_evidence:
+            out["dp"] = dp_evidence
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_blur(B, H, W, C, args.sigma, apps)
         print(json.dumps(out), flush=True)

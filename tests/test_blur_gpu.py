@@ -236,3 +236,22 @@ def test_fused_critic_batch_equals_separate_launches(tmp_path, monkeypatch):
         return out, gan.discriminator.store.theta.clone(), gan.generator.store.theta.clone()
     a, b = run(False), run(True)
     assert a[0] == b[0] and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+
+
+@pytest.mark.parametrize("shape,std", [((128, 128, 128, 3), 5.0), ((64, 256, 256, 3), 5.0), ((64, 256, 256, 3), 23.5), ((64, 256, 256, 3), 42.34),
+                                       ((256, 64, 64, 3), 5.0), ((768, 64, 64, 3), 5.0)])
+def test_blur_at_full_baseline_batches_matches_oracle_on_sampled_images(shape, std):
+    """The FULL-SIZE launches of BASELINE.json's configurations -- C2 (256 and the critic's 3 x 256 images of 64x64), C4 (128 images of
+    128x128), C5 (64 images of 256x256 at 31 / 143 / 255 taps: the fused strips and the 32-row panel kernel with its XCD-aware
+    image placement) -- against the float64 oracle (gaussian_blur.py:50-132) on a SAMPLE of their images: the blur is per image, so
+    images from the first, a middle and the last workgroup groups pin the whole-batch launch where the property checks above only
+    relate its outputs to each other."""
+    B, H, W, C = shape
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, size=shape).astype(np.float32)
+    y, (ks, se, nt) = _run(x, std)
+    picks = sorted({0, 1, 7, 8, B // 2 - 1, B // 2, B - 9, B - 1})
+    ref = O.blur_images(x[picks].astype(np.float64), std)
+    np.testing.assert_allclose(y[picks], ref, rtol=POINT_RTOL, atol=POINT_ATOL * 4)
+    # ... and no image of the batch is left unwritten or shared: every image differs from its neighbour and from the input
+    assert all(not np.array_equal(y[i], y[i + 1]) for i in range(0, B - 1, max(1, B // 16)))

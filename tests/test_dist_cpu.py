@@ -230,3 +230,28 @@ def test_step_key_normalises_numpy_hyperparameters():
     assert wgan._plain(np.int64(3)) == 3 and type(wgan._plain(np.int64(3))) is int
     assert wgan._plain(True) is True and wgan._plain("adam") == "adam"
     assert len(wgan._env_switches()) == len(wgan._KEY_ENV)
+
+
+def _evidence_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from blurred_gan_amd import dist
+    dist.init_from_env(backend="gloo")
+    ev = dist.evidence()
+    json.dump(ev, open(os.path.join(out_dir, f"ev_{rank}.json"), "w"))
+    dist.shutdown()
+
+
+def test_dp_evidence_counts_the_peers_through_the_communicator(tmp_path):
+    """bench.py's `dp` object with two gloo ranks on the CPU: the peer count comes from an all-reduce of ones
+    through the group, not from WORLD_SIZE; every rank reports the same picture; no RCCL claim on a gloo group."""
+    import json
+    mp.spawn(_evidence_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    ev = [json.load(open(tmp_path / f"ev_{r}.json")) for r in range(2)]
+    assert ev[0] == ev[1]
+    assert ev[0]["backend"] == "gloo" and ev[0]["collective_nranks"] == 2 and ev[0]["world_size_env"] == 2
+    assert len(ev[0]["devices"]) == 2 and "rccl_nranks" not in ev[0] and ev[0]["collective_route"] == "torch"
+    from blurred_gan_amd import dist
+    assert dist.evidence() == {}                              # no group joined in this process

@@ -57,9 +57,10 @@ def main():
     a = ap.parse_args()
     B = a.batch
     torch.manual_seed(0)
-    # %peak: SURVEY 8d's count (every tap at every output position); %useful: only the taps that meet real data (bg_prof_get_useful) --
-    # the column that cannot exceed 100 (on 4x4 maps 51 % of the 25 taps land on the SAME zero padding and are skipped, not multiplied)
-    print(f"{'layer':<20}{'op':<8}{'ms':>9}{'TFLOP/s':>10}{'%peak':>8}{'%useful':>9}  kernels")
+    # Rates are priced by USEFUL flops (bg_prof_get_useful: only the taps that meet real data -- on 4x4 maps 51 % of the 25 taps land on
+    # the SAME zero padding and are skipped, not multiplied): the column that cannot exceed 100.  SURVEY 8d's count (every tap at every
+    # output position; the figure roofline.achieved keeps) follows in brackets and CAN read above the peak on small maps.
+    print(f"{'layer':<20}{'op':<8}{'ms':>9}{'TFLOP/s':>10}{'%peak':>8}  {'[8d count: TFLOP/s, %]':<24}  kernels")
     tot = {}
     for name, H, W, Ci, Co, s in LAYERS[a.arch]:
         if a.only and not any(o in name for o in a.only.split(",")):
@@ -90,9 +91,10 @@ def main():
             tot[op][0] += ms
             tot[op][1] += fl
             tot[op][2] += us
-            print(f"{name:<20}{op:<8}{ms:9.4f}{tf:10.2f}{100 * tf / 157.3:8.1f}{100 * us / (ms * 1e-3) / 1e12 / 157.3:9.1f}  {','.join(names)}")
+            tu = us / (ms * 1e-3) / 1e12
+            print(f"{name:<20}{op:<8}{ms:9.4f}{tu:10.2f}{100 * tu / 157.3:8.1f}  [{tf:7.2f}, {100 * tf / 157.3:5.1f}]{'':<8}  {','.join(names)}")
     for op, (ms, fl, us) in tot.items():
-        print(f"{'TOTAL':<20}{op:<8}{ms:9.4f}{fl / (ms * 1e-3) / 1e12:10.2f}{100 * fl / (ms * 1e-3) / 1e12 / 157.3:8.1f}{100 * us / (ms * 1e-3) / 1e12 / 157.3:9.1f}")
+        print(f"{'TOTAL':<20}{op:<8}{ms:9.4f}{us / (ms * 1e-3) / 1e12:10.2f}{100 * us / (ms * 1e-3) / 1e12 / 157.3:8.1f}  [{fl / (ms * 1e-3) / 1e12:7.2f}, {100 * fl / (ms * 1e-3) / 1e12 / 157.3:5.1f}]")
 
 
 if __name__ == "__main__":

@@ -7,8 +7,13 @@ from blurred_gan_amd import ops
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__))))
 from bench_conv import LAYERS
 
-B = 256
+B = int(os.environ.get("PROBE_BATCH", "256"))
+# PROBE_PRIO=1: the data gradient (the backward's critical chain) on a HIGH-priority stream, the filter gradient on a default one:
+# does the low-priority kernel fill the under-occupied tail of the other instead of taking its share of every CU?
+PRIO = os.environ.get("PROBE_PRIO") == "1"
 side = torch.cuda.Stream()
+main = torch.cuda.Stream(priority=-1) if PRIO else None
+print("stream priority range:", torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else "n/a", "high-priority main:", PRIO)
 for name, H, W, Ci, Co, s in LAYERS["celeba64"]:
     if Ci < 16 or Co < 16:
         continue
@@ -29,12 +34,20 @@ for name, H, W, Ci, Co, s in LAYERS["celeba64"]:
         ops.conv2d_bwd_filter(x, dy, dw, 5, s, 0.0, 1.0, ws)
     def par():
         ev = torch.cuda.Event(); ev.record()
-        ops.conv2d_bwd_data(dy, w, dx, 5, s, epi)
+        if PRIO:
+            with torch.cuda.stream(main):
+                main.wait_event(ev)
+                ops.conv2d_bwd_data(dy, w, dx, 5, s, epi)
+                e1 = torch.cuda.Event(); e1.record()
+        else:
+            ops.conv2d_bwd_data(dy, w, dx, 5, s, epi)
         with torch.cuda.stream(side):
             side.wait_event(ev)
             ops.conv2d_bwd_filter(x, dy, dw, 5, s, 0.0, 1.0, ws)
             e2 = torch.cuda.Event(); e2.record()
         torch.cuda.current_stream().wait_event(e2)
+        if PRIO:
+            torch.cuda.current_stream().wait_event(e1)
     def timeit(fn, n=20):
         for _ in range(3): fn()
         torch.cuda.synchronize()
