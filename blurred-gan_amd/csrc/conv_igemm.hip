@@ -221,38 +221,68 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
   // MFMAs of tile s execute -- no LDS round trip is exposed after the barrier.
   // Loads have two full steps (~2 x 1024 MFMA cycles) to return: enough for an L2 miss served by the Infinity Cache /
   // HBM, which the weight-streaming small-M layers (K = 6400) hit on most steps.
+  // ---- VALU-lean loader (round 5).  On gfx950 the fp32 MFMA runs on the SIMD's vector datapath: tools/probes/mfma_valu_dual.hip --
+  // two v_add_u32 (or one v_cmp + v_cndmask pair, or two v_pk_fma_f32) issued per v_mfma_f32_32x32x2_f32 take the matrix rate from
+  // 152 to 134 TFLOP/s, four take it to 118: every vector instruction in the K loop is matrix time lost one for one, whichever
+  // wave issues it.  The loader used to spend ~20 of them per step (per row: two adds and two compares for the SAME-padding test, an
+  // add and a select for the offset; per weight row an add and a select).  Now
+  //  * the padding test of a row is a BIT MASK over the unit's compact tap list, taken once in the prologue;
+  //  * a row's offset is rebuilt only when the TAP changes (every Ck / BK steps): bit, add, shift-or = 3 instructions, bit 31 set
+  //    = poisoned (the buffer range check returns zeros);
+  //  * the channel chunk of a step and the whole weight offset travel in the buffer instruction's SCALAR offset (non-negative by
+  //    construction), so the weight rows need no vector instruction at all and the activation rows none between tap changes;
+  //  * steps past the unit's end (the pipeline's look-ahead, the padded odd step) read through a descriptor of zero records.
+  // Same addresses, same zeros: results are bit-identical.
   int g_tq = s_begin / kchunks;                          // compact tap index / channel chunk of the NEXT gload (wave-uniform)
   int g_kc = s_begin - g_tq * kchunks;
-  int g_tp = taplist[min(g_tq, ntaps_c - 1)];            // its packed tap, read one gload ahead of its use
-  int g_left = nsteps;                                   // steps still to load; <= 0: padded step, poisoned offsets load zeros
+  int g_left = nsteps;                                   // steps still to load; <= 0: padded step, the null descriptor loads zeros
+  unsigned a_bad[AP];                                    // bit t: compact tap t falls on zero padding for this row (or the row is past M)
+#pragma unroll
+  for (int i = 0; i < AP; ++i) a_bad[i] = 0u;
+  for (int t = 0; t < ntaps_c; ++t) {
+    const int tp = taplist[t];
+    const int dy = bg::tap_dy(tp), dx = bg::tap_dx(tp);
+#pragma unroll
+    for (int i = 0; i < AP; ++i)
+      a_bad[i] |= ((unsigned)(a_y[i] + dy) < (unsigned)p.Hs && (unsigned)(a_x[i] + dx) < (unsigned)p.Ws) ? 0u : (1u << t);
+  }
+  const __amdgpu_buffer_rsrc_t rsNull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0, 0x00020000);
+  unsigned a_voff[AP];                                   // byte offset of the row's quad at the current tap (bit 31: poisoned)
+  unsigned g_woff = 0;                                   // weight offset of the current tap, without the channel chunk (scalar)
+  auto new_tap = [&]() {                                 // wave-uniform: runs when the load stream moves to another tap
+    const int tq = min(g_tq, ntaps_c - 1);
+    const int tp = __builtin_amdgcn_readfirstlane(taplist[tq]);
+    const int dy = bg::tap_dy(tp), dx = bg::tap_dx(tp);
+    const unsigned tapoff = (unsigned)(((dy * p.Ws + dx) * p.Ck) * 4);
+    g_woff = (unsigned)((bg::tap_wi(tp) * p.N * p.Ck) * 4);
+#pragma unroll
+    for (int i = 0; i < AP; ++i) a_voff[i] = (((a_bad[i] >> tq) & 1u) << 31) | (a_off[i] + tapoff);
+  };
+  new_tap();
   auto gload = [&](float4 (&rA)[AP], float4 (&rB)[BP]) {
     const bool live = g_left > 0;
-    const int tp = g_tp;
-    const int c0 = g_kc * BK;
-    const int dy = bg::tap_dy(tp), dx = bg::tap_dx(tp);
-    const unsigned tapoff = (unsigned)(((dy * p.Ws + dx) * p.Ck + c0) * 4);
-    const unsigned woff = (unsigned)((bg::tap_wi(tp) * p.N * p.Ck + c0) * 4);
+    const int c0b = g_kc * BK * 4;                       // this step's channel chunk, in bytes: the scalar offset
+    const __amdgpu_buffer_rsrc_t ra = live ? rsA : rsNull, rb = live ? rsB : rsNull;
 #pragma unroll
     for (int i = 0; i < AP; ++i) {
-      const bool ok = live && (unsigned)(a_y[i] + dy) < (unsigned)p.Hs && (unsigned)(a_x[i] + dx) < (unsigned)p.Ws;
 #if defined(BG_DIAG) && defined(IGEMM_NO_A)
-      rA[i] = make_float4(ok ? 1.f : 0.f, 0.5f, (float)tapoff, 0.25f);      // knock-out: no gather traffic, same data flow
+      rA[i] = make_float4((live && !(a_voff[i] >> 31)) ? 1.f : 0.f, 0.5f, (float)c0b, 0.25f);      // knock-out: no gather traffic, same data flow
 #else
-      rA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsA, ok ? a_off[i] + tapoff : kOob, 0, 0));
+      rA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(ra, a_voff[i], c0b, 0));
 #endif
     }
 #pragma unroll
     for (int i = 0; i < BP; ++i)
 #if defined(BG_DIAG) && defined(IGEMM_NO_B)
-      rB[i] = make_float4(live ? 1.f : 0.f, 0.5f, (float)woff, 0.25f);
+      rB[i] = make_float4(live ? 1.f : 0.f, 0.5f, (float)g_woff, 0.25f);
 #else
-      rB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsB, (b_off[i] == kOob || !live) ? kOob : b_off[i] + woff, 0, 0));
+      rB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rb, b_off[i], (int)g_woff + c0b, 0));
 #endif
     --g_left;
     if (++g_kc == kchunks) {
       g_kc = 0;
       ++g_tq;
-      g_tp = taplist[min(g_tq, ntaps_c - 1)];
+      new_tap();
     }
   };
   auto lstore = [&](int buf, const float4 (&rA)[AP], const float4 (&rB)[BP]) {
@@ -432,12 +462,12 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
       }
   };
   // steps left in the phase being accumulated (pm == 1: the workgroup's whole K slice); phases without a live tap store zeros
-  int c_q = 0, c_left = pm == 1 ? nsteps : phase_steps[0];
+  int c_q = 0, c_left = pm == 1 ? nsteps : __builtin_amdgcn_readfirstlane(phase_steps[0]);       // scalar: a compare in the K loop, not a vector one
   auto phase_done = [&]() {
     do {
       epilogue(c_q);
       ++c_q;
-      c_left = c_q < pm ? phase_steps[c_q] : -1;
+      c_left = c_q < pm ? __builtin_amdgcn_readfirstlane(phase_steps[c_q < pm ? c_q : 0]) : -1;
     } while (c_left == 0);
   };
   if (c_left == 0) phase_done();
