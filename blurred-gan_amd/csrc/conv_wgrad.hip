@@ -162,10 +162,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
       t_r[i] = r;
       t_oy[i] = 0;
       t_ox[i] = 0;
-      t_off[i] = (unsigned)(r * p.H * p.W * p.Ci * 4 + a_coloff);
+      t_off[i] = a_col_ok ? (unsigned)(r * p.H * p.W * p.Ci * 4 + a_coloff) : kOob;
     }
 #pragma unroll
-    for (int i = 0; i < BP; ++i) b_off[i] = (unsigned)((brow + i * RPP_B) * HoWo * p.Co * 4 + b_coloff);
+    for (int i = 0; i < BP; ++i) b_off[i] = b_col_ok ? (unsigned)((brow + i * RPP_B) * HoWo * p.Co * 4 + b_coloff) : kOob;
   }
   int s_m0 = m_begin;                                       // chunk origin of the NEXT gload (wave-uniform)
   // P2 == 2 (position-major): only the chunks whose output position is inside the image for this tap are visited.  They
@@ -196,12 +196,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
         const int b0 = q_bc * BKP, pos = q_oh * p.Wo + q_ow;
         const unsigned offS = (unsigned)(((b0 * p.H + q_oh * p.s + dyk) * p.W + q_ow * p.s + dxk) * p.Ci * 4);
         const unsigned offY = (unsigned)((b0 * HoWo + pos) * p.Co * 4);
+        // the per-thread part of an offset never changes here (t_off / b_off, poisoned for channel quads past Ci / Co); the chunk's
+        // origin is wave-uniform and non-negative (only live positions are visited): it rides in the instruction's scalar offset
+        // and the loads cost no vector instruction at all
 #pragma unroll
         for (int i = 0; i < AP; ++i)
-          regA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, a_col_ok ? t_off[i] + offS : kOob, 0, 0));
+          regA[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsX, t_off[i], (int)offS, 0));
 #pragma unroll
         for (int i = 0; i < BP; ++i)
-          regB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, b_col_ok ? b_off[i] + offY : kOob, 0, 0));
+          regB[i] = __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(rsY, b_off[i], (int)offY, 0));
         --q_left;
         if (++q_bc == q_nb) {
           q_bc = 0;
@@ -287,14 +290,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_v3_kernel(const WgradParams p)
     // sched_barrier pins that order -- left alone, the scheduler sinks each ds_read to just before its MFMA and
     // the LDS latency is exposed once per k-pair.
     float af[2][PF][MI], bf[2][PF][NI];
+    typedef const volatile __attribute__((address_space(3))) float* lds_cvf;      // volatile, but still an LDS (ds_read) access
     auto fetch = [&](int slot, int grp) {
 #pragma unroll
       for (int q = 0; q < PF; ++q) {
         const int krow = 2 * (wk + (grp * PF + q) * WAVES_K) + fk;
+        // volatile: each element stays ONE ds_read_b32 with its 16-bit immediate offset.  Left to the compiler, the two elements of
+        // a k-row merge into a ds_read2_b32, whose 8-bit offsets do not reach the next k-row -- so it rebuilt the address with a
+        // v_add_u32 per read, 28 vector instructions per 64 MFMAs, and on gfx950 every vector instruction in an fp32-MFMA loop is
+        // matrix time lost one for one (tools/probes/mfma_valu_dual.hip); an LDS read costs a quarter of that
 #pragma unroll
-        for (int i = 0; i < MI; ++i) af[slot][q][i] = sa[krow * BM + i * 32];
+        for (int i = 0; i < MI; ++i) af[slot][q][i] = *(lds_cvf)(sa + krow * BM + i * 32);
 #pragma unroll
-        for (int j = 0; j < NI; ++j) bf[slot][q][j] = sb[krow * BN + j * 32];
+        for (int j = 0; j < NI; ++j) bf[slot][q][j] = *(lds_cvf)(sb + krow * BN + j * 32);
       }
     };
     fetch(0, 0);
@@ -1622,7 +1630,8 @@ WgradPlan plan_wgrad(int B, int H, int W, int Ci, int Co, int k, int s) {
   static const int old_plan = getenv("BG_WGRAD_OLD_PLAN") ? 1 : 0;
   // position-major small maps skip their all-padding chunks: workgroup lengths differ 4x between centre and corner taps, and
   // more, shorter workgroups balance better than the round model predicts (measured: G1 0.33 ms at 800 workgroups, 0.40 at 400)
-  const bool skipping = Ho * Wo <= 16 && B >= 128 && (B & (B - 1)) == 0;
+  static const int pm_pow2_plan = getenv("BG_WGRAD_PM_POW2") ? 1 : 0;
+  const bool skipping = Ho * Wo <= 16 && B >= 128 && (pm_pow2_plan ? (B & (B - 1)) == 0 : B % 128 == 0);
   if (old_plan || pl.taps_in_grid != 1 || skipping) {     // tap-grouped kernel: measured slower with the model's single full round (0.35 vs 0.28 ms)
     static const int tgt_env = getenv("BG_WGRAD_TARGET") ? atoi(getenv("BG_WGRAD_TARGET")) : 0;   // tuning aid
     // ~3 workgroups per CU; the tap-grouped kernel (3 resident per CU) measured best at two full rounds (G5: 0.30 -> 0.27 ms)
@@ -1705,7 +1714,11 @@ int bg_conv2d_bwd_filter(const float* x, const float* dy, float* dw, int B, int 
     p.pow2 = ((1 << p.lg_w) == p.Wo && (1 << p.lg_h) == p.Ho) ? 1 : 0;
     p.lg_b = lg2(B);
     static const int no_pm = getenv("BG_NO_POS_MAJOR") ? 1 : 0;
-    if (p.pow2 && !no_pm && (1 << p.lg_b) == B && B >= 128 && p.Ho * p.Wo <= 16) p.pow2 = 2;   // 8x8: the same-channel stride of position-major rows costs more than the skipped chunks save
+    // position-major: a chunk = BKP images at ONE output position, so the batch only has to be whole chunks (the critic's merged
+    // pass runs 3 x 256 = 768 samples); BG_WGRAD_PM_POW2=1 restores the power-of-two rule of rounds 1-4
+    static const int pm_pow2 = getenv("BG_WGRAD_PM_POW2") ? 1 : 0;
+    const bool b_ok = pm_pow2 ? (1 << p.lg_b) == B : B % 128 == 0;
+    if (p.pow2 && !no_pm && b_ok && B >= 128 && p.Ho * p.Wo <= 16) p.pow2 = 2;   // 8x8: the same-channel stride of position-major rows costs more than the skipped chunks save
     p.x_bytes = (unsigned)((size_t)B * H * W * Cin * sizeof(float));
     p.dy_bytes = (unsigned)((size_t)p.M * Cout * sizeof(float));
   }

@@ -22,6 +22,7 @@ CASES = [
     (2, 20, 128, 16, 3, 1), (2, 24, 256, 3, 16, 2),                           # ... on 128-pixel rows (8 waves per workgroup)
     (128, 4, 4, 64, 64, 1), (128, 8, 8, 32, 64, 2), (128, 8, 8, 64, 32, 2),   # position-major tiles: padding taps skipped (64- and 128-row tiles)
     (1024, 16, 16, 16, 32, 2),                                                 # position-major AND the four phases merged in one workgroup
+    (384, 4, 4, 128, 256, 2), (384, 8, 8, 64, 128, 2),                         # position-major filter gradient at a batch that is whole 128-image chunks but no power of two (the merged critic pass: 3 x 128)
     (3, 64, 64, 16, 32, 2), (2, 128, 128, 16, 32, 2), (5, 12, 128, 16, 32, 2), (2, 4, 64, 16, 32, 2),   # row-staged 16-channel kernels (C4's outer layers)
     # strip-resident filter gradient (Ci % 32 == 0, Co % 64 == 0, stride 2, Wo = 8 / 16 / 32): one strip per image, several strips per
     # image, non-square maps, a strip count the workgroups do not divide, several channel tiles
