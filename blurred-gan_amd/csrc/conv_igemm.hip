@@ -249,9 +249,11 @@ __global__ __launch_bounds__(WAVES_M * WAVES_N * 64, (BM == 64 && BN == 64 && !S
   const __amdgpu_buffer_rsrc_t rsNull = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, 0, 0x00020000);
   unsigned a_voff[AP];                                   // byte offset of the row's quad at the current tap (bit 31: poisoned)
   unsigned g_woff = 0;                                   // weight offset of the current tap, without the channel chunk (scalar)
+  int g_tp_v = taplist[min(g_tq, ntaps_c - 1)];          // the NEXT tap's packed entry, read one tap ahead of its use (no LDS wait then)
   auto new_tap = [&]() {                                 // wave-uniform: runs when the load stream moves to another tap
     const int tq = min(g_tq, ntaps_c - 1);
-    const int tp = __builtin_amdgcn_readfirstlane(taplist[tq]);
+    const int tp = __builtin_amdgcn_readfirstlane(g_tp_v);
+    g_tp_v = taplist[min(g_tq + 1, ntaps_c - 1)];
     const int dy = bg::tap_dy(tp), dx = bg::tap_dx(tp);
     const unsigned tapoff = (unsigned)(((dy * p.Ws + dx) * p.Ck) * 4);
     g_woff = (unsigned)((bg::tap_wi(tp) * p.N * p.Ck) * 4);
