@@ -263,4 +263,35 @@ int try_conv_c16(int bwd_data, const float* a, const float* w, float* c, int B, 
 int try_conv_rows_gather(int bwd_data, const float* a, const float* w, float* c, int B, int H, int W, int Cin, int Cout, int k, int s,
                          const bg_epilogue* epi, void* stream, int* taken);
 
+// Rows of float4 from global memory into LDS with SU loads in flight per thread (256 threads).  `src(r, c4)` returns the address of
+// float4 c4 of row r or nullptr (zero padding / halo).  The plain form -- one load, one LDS write per iteration -- waits for every
+// load before the next is issued: a chain of global round trips per staged block (round 5: that chain, not the matrix work, was
+// most of a workgroup's time in the thin kernels).
+template <int SU, typename SrcFn>
+__device__ __forceinline__ void stage_rows_f4(float* lds, int nrows, int q4, int row_stride, int tid, SrcFn src) {
+  const int tot = nrows * q4;
+  for (int i0 = tid; i0 < tot; i0 += 256 * SU) {
+    float4 v[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int idx = i0 + u * 256;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < tot) {
+        const int r = idx / q4, c4 = idx - r * q4;
+        const float* s = src(r, c4);
+        if (s) v[u] = *reinterpret_cast<const float4*>(s);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int idx = i0 + u * 256;
+      if (idx < tot) {
+        const int r = idx / q4, c4 = idx - r * q4;
+        *reinterpret_cast<float4*>(lds + (size_t)r * row_stride + c4 * 4) = v[u];
+      }
+    }
+  }
+}
+
+
 }  // namespace bg

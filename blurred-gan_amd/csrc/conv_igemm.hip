@@ -610,6 +610,99 @@ __global__ __launch_bounds__(256) void conv_thin_n_patch_kernel(const GatherPara
   }
 }
 
+// The same for ALL sub-pixel phases of a transposed conv from ONE staged patch (MNIST's ConvT 64 -> 1 and the data gradient of its
+// Conv 1 -> 64: 14 x 14 anchors, four phases).  The per-phase form above stages the same 14 x 14 x 64 source four times, once per
+// (image, phase) workgroup, each with an 18 x 18 pixel patch of 88 KB -- one workgroup per CU, four rounds at batch 256, 81 us for
+// 13.6 MB of traffic.  Here a workgroup owns an anchor tile of one image, its patch carries the union of the phases' halos and only
+// the rows / columns the map really has (16 x 16 pixels, 70 KB: two workgroups per CU), and every thread walks the phases of its
+// anchor.  Same taps in the same order per output: bit-identical to the per-phase kernel.
+template <int CK, int kThinTW, int N>
+__global__ __launch_bounds__(256) void conv_thin_n_patch_all_kernel(const GatherParams p, int ha_max, int wa_max, int ntap_w) {
+  extern __shared__ __attribute__((aligned(16))) float patch[];
+  constexpr int kThinTH = 256 / kThinTW;
+  constexpr int CS = CK + 4, Q = CK / 4;
+  const int b = blockIdx.z;
+  const int a0 = blockIdx.y * kThinTH, x0 = blockIdx.x * kThinTW;
+  const int th = min(kThinTH, ha_max - a0), tw = min(kThinTW, wa_max - x0);      // anchors this tile really has
+  int dmin_y = 127, dmax_y = -127, dmin_x = 127, dmax_x = -127;                 // union halo of all phases
+  for (int q = 0; q < p.nphase; ++q) {
+    const GatherPhase& g = p.ph[q];
+    for (int t = 0; t < g.ntaps; ++t) {
+      const int dy = bg::tap_dy(g.tap[t]), dx = bg::tap_dx(g.tap[t]);
+      dmin_y = min(dmin_y, dy); dmax_y = max(dmax_y, dy);
+      dmin_x = min(dmin_x, dx); dmax_x = max(dmax_x, dx);
+    }
+  }
+  const int PH = (th - 1) * p.ss + (dmax_y - dmin_y) + 1;
+  const int PW = (tw - 1) * p.ss + (dmax_x - dmin_x) + 1;
+  const int sy0 = a0 * p.ss + dmin_y, sx0 = x0 * p.ss + dmin_x;
+  const float* src = p.A + (size_t)b * p.Hs * p.Ws * CK;
+  // eight loads in flight per thread: one load -> one LDS write per iteration is a chain of global round trips (16 of them for
+  // a 16 x 16 x 64 patch), which is what a workgroup of this kernel spent most of its time on
+  constexpr int SU = 8;
+  const int total = PH * PW * Q;
+  for (int i0 = threadIdx.x; i0 < total; i0 += 256 * SU) {
+    float4 v[SU];
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int idx = i0 + u * 256;
+      const int q = idx % Q, pix = idx / Q;
+      const int py = pix / PW, px = pix - py * PW;
+      const int sy = sy0 + py, sx = sx0 + px;
+      v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (idx < total && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
+        v[u] = *reinterpret_cast<const float4*>(src + ((size_t)sy * p.Ws + sx) * CK + q * 4);
+    }
+#pragma unroll
+    for (int u = 0; u < SU; ++u) {
+      const int idx = i0 + u * 256;
+      if (idx < total) *reinterpret_cast<float4*>(patch + (idx / Q) * CS + (idx % Q) * 4) = v[u];
+    }
+  }
+  // the weights of every tap go to LDS as well: read from global they are wave-uniform scalar loads INSIDE the channel loop, each
+  // waited for before its four FMAs -- 400 dependent round trips per thread, 50 us for a 3 us kernel
+  float* wl = patch + PH * PW * CS;
+  for (int idx = threadIdx.x; idx < ntap_w * N * Q; idx += 256)
+    *reinterpret_cast<float4*>(wl + idx * 4) = *reinterpret_cast<const float4*>(p.Wt + (size_t)idx * 4);
+  __syncthreads();
+  const int ty = threadIdx.x / kThinTW, tx = threadIdx.x % kThinTW;
+  if (ty >= th || tx >= tw) return;
+  const float* base = patch + ((ty * p.ss - dmin_y) * PW + tx * p.ss - dmin_x) * CS;
+  const int a_ = a0 + ty, bx = x0 + tx;
+  for (int ph = 0; ph < p.nphase; ++ph) {
+    const GatherPhase& g = p.ph[ph];
+    if (a_ >= g.Ha || bx >= g.Wa) continue;
+    float acc[N];
+#pragma unroll
+    for (int n = 0; n < N; ++n) acc[n] = 0.f;
+    for (int t = 0; t < g.ntaps; ++t) {
+      const int tp = g.tap[t];
+      const float* a = base + (bg::tap_dy(tp) * PW + bg::tap_dx(tp)) * CS;
+      const float* w = wl + bg::tap_wi(tp) * N * CK;                // same address in every lane: LDS broadcast
+      float4 av[Q];                                                 // the pixel's channels at this tap, all reads in flight at once
+#pragma unroll
+      for (int q = 0; q < Q; ++q) av[q] = *reinterpret_cast<const float4*>(a + q * 4);
+#pragma unroll
+      for (int q = 0; q < Q; ++q) {
+#pragma unroll
+        for (int n = 0; n < N; ++n) {
+          const float4 wv = *reinterpret_cast<const float4*>(w + n * CK + q * 4);
+          acc[n] = fmaf(av[q].x, wv.x, acc[n]);
+          acc[n] = fmaf(av[q].y, wv.y, acc[n]);
+          acc[n] = fmaf(av[q].z, wv.z, acc[n]);
+          acc[n] = fmaf(av[q].w, wv.w, acc[n]);
+        }
+      }
+    }
+    const size_t dst = ((size_t)b * p.Hd + a_ * p.ds + g.py) * p.Wd + bx * p.ds + g.px;
+#pragma unroll
+    for (int n = 0; n < N; ++n) {
+      const size_t idx = dst * N + n;
+      p.C[idx] = bg::apply_epilogue(p, acc[n], idx, n);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // thin-N forward on MFMA (stride 1, N*k <= 16; the generator's last conv 32->3 / 16->3):
 // the channel contraction runs on v_mfma_f32_16x16x4_f32 with the (kw, n) pairs as the 16 MFMA columns,
@@ -817,6 +910,93 @@ __global__ __launch_bounds__(256) void conv_thin_k_mfma_kernel(const GatherParam
         const int n = n0 + j * 32 + i;
         if (n < p.N) {
           const size_t idx = dst * p.N + n;
+          p.C[idx] = bg::apply_epilogue(p, acc[j][r], idx, n);
+        }
+      }
+    }
+  }
+}
+
+// The same contraction with BOTH operands read straight from global memory (round 5).  The staged form above is a latency chain
+// on the layers it serves (MNIST's Conv 1 -> 64: 2 workgroups per image, 26 MFMAs per wave): a gather loop for the weight panel,
+// a loop for the patch, a barrier, then a handful of MFMAs and the stores -- 18-24 us per launch for 10 MB of traffic and 0.8 us of
+// matrix work.  Here a lane issues its whole operand stream up front -- per k-pair one activation (its pixel at that tap, poisoned
+// offset = zero padding) and NT weights (its column) through buffer descriptors, sixteen k-pairs in flight -- and the only LDS use is
+// a 104-entry table of unpacked taps.  Same products in the same order: bit-identical to the staged kernel.
+template <int NT>
+__global__ __launch_bounds__(256) void conv_thin_k_direct_kernel(const GatherParams p) {
+  __shared__ int ktab[kTkMaxKF];
+  const int phase = blockIdx.z % p.nphase, b = blockIdx.z / p.nphase;
+  const GatherPhase& g = p.ph[phase];
+  const int a0 = blockIdx.y * kTkTH, x0 = blockIdx.x * kTkTW;
+  if (a0 >= g.Ha || x0 >= g.Wa) return;
+  const int Ck = p.Ck, N = p.N;
+  const int KF = g.ntaps * Ck, KP = (KF + 1) >> 1;
+  const int tid = threadIdx.x;
+  if (tid < 2 * KP) {                      // entry k = tap * Ck + c: dy + 64 | dx + 64 << 8 | c << 16 | weight tap << 20; -1 past KF
+    int e = -1;
+    if (tid < KF) {
+      const int t = tid / Ck, c = tid - t * Ck;
+      const int tp = g.tap[t];
+      e = (bg::tap_dy(tp) + 64) | ((bg::tap_dx(tp) + 64) << 8) | (c << 16) | (bg::tap_wi(tp) << 20);
+    }
+    ktab[tid] = e;
+  }
+  __syncthreads();
+  constexpr unsigned kOob = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.Wt), 0, (int)p.w_bytes, 0x00020000);
+  const int lane = tid & 63, wave = tid >> 6;
+  const int i = lane & 31, half = lane >> 5;
+  const int ty = 2 * wave + (i >> 4), tx = i & 15;
+  const int ay = (a0 + ty) * p.ss, ax = (x0 + tx) * p.ss;
+  const bool pix_ok = a0 + ty < g.Ha && x0 + tx < g.Wa;
+  const int img = b * p.Hs;
+  floatx16 acc[NT];
+#pragma unroll
+  for (int j = 0; j < NT; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  constexpr int D = 16;                    // k-pairs in flight (MNIST: 13 k-pairs = one round of loads)
+  for (int kp0 = 0; kp0 < KP; kp0 += D) {
+    unsigned av[D], bv[D][NT];                  // raw bits of the loaded floats
+#pragma unroll
+    for (int d = 0; d < D; ++d) {
+      const int kp = kp0 + d;
+      const int e = kp < KP ? ktab[2 * kp + half] : -1;
+      unsigned aoff = kOob, woff[NT];
+#pragma unroll
+      for (int j = 0; j < NT; ++j) woff[j] = kOob;
+      if (e >= 0) {
+        const int sy = ay + (e & 0xff) - 64, sx = ax + ((e >> 8) & 0xff) - 64, c = (e >> 16) & 0xf, wi = e >> 20;
+        if (pix_ok && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws) aoff = (unsigned)(((img + sy) * p.Ws + sx) * Ck + c) * 4u;
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          if (j * 32 + i < N) woff[j] = (unsigned)((wi * N + j * 32 + i) * Ck + c) * 4u;
+      }
+      av[d] = __builtin_amdgcn_raw_buffer_load_b32(rsA, aoff, 0, 0);
+#pragma unroll
+      for (int j = 0; j < NT; ++j) bv[d][j] = __builtin_amdgcn_raw_buffer_load_b32(rsW, woff[j], 0, 0);
+    }
+#pragma unroll
+    for (int d = 0; d < D; ++d)
+      if (kp0 + d < KP) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(__builtin_bit_cast(float, av[d]), __builtin_bit_cast(float, bv[d][j]), acc[j], 0, 0, 0);
+      }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int pi = (r & 3) + 8 * (r >> 2) + 4 * half;
+    const int a_ = a0 + 2 * wave + (pi >> 4), bx = x0 + (pi & 15);
+    if (a_ < g.Ha && bx < g.Wa) {
+      const size_t dst = ((size_t)b * p.Hd + a_ * p.ds + g.py) * p.Wd + bx * p.ds + g.px;
+#pragma unroll
+      for (int j = 0; j < NT; ++j) {
+        const int n = j * 32 + i;
+        if (n < N) {
+          const size_t idx = dst * N + n;
           p.C[idx] = bg::apply_epilogue(p, acc[j][r], idx, n);
         }
       }
@@ -1265,6 +1445,50 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
       tiles_x = std::max(tiles_x, (int)bg::cdiv(p.ph[i].Wa, kThinTW));
       tiles_y = std::max(tiles_y, (int)bg::cdiv(p.ph[i].Ha, kThinTH));
     }
+    // all phases from one staged patch (transposed convs): union halo, the tile clipped to the anchors the map has
+    static const int no_all = getenv("BG_NO_THIN_N_ALL") ? 1 : 0;
+    if (p.nphase > 1 && !no_all && p.B <= 65535) {
+      int mny = 127, mxy = -127, mnx = 127, mxx = -127, hamax = 0, wamax = 0;
+      for (int i = 0; i < p.nphase; ++i) {
+        hamax = std::max(hamax, p.ph[i].Ha); wamax = std::max(wamax, p.ph[i].Wa);
+        for (int t = 0; t < p.ph[i].ntaps; ++t) {
+          const int dy = bg::tap_dy(p.ph[i].tap[t]), dx = bg::tap_dx(p.ph[i].tap[t]);
+          mny = std::min(mny, dy); mxy = std::max(mxy, dy); mnx = std::min(mnx, dx); mxx = std::max(mxx, dx);
+        }
+      }
+      const size_t PHu = (size_t)(std::min(kThinTH, hamax) - 1) * p.ss + (mxy - mny) + 1;
+      const size_t PWu = (size_t)(std::min(kThinTW, wamax) - 1) * p.ss + (mxx - mnx) + 1;
+      const size_t lds_all = (PHu * PWu * (size_t)(p.Ck + 4) + (size_t)ntap_w * p.N * p.Ck) * sizeof(float);
+      if (lds_all <= 150 * 1024) {
+#define BG_TNA1(CKv, TWv, Nv)                                                                                     \
+  do {                                                                                                            \
+    BG_LDS_ATTR_ONCE_V((conv_thin_n_patch_all_kernel<CKv, TWv, Nv>), 150 * 1024);                               \
+    bg::launch((conv_thin_n_patch_all_kernel<CKv, TWv, Nv>), grid, dim3(256), lds_all, L.s, p, hamax, wamax, ntap_w); \
+  } while (0)
+#define BG_TNA2(CKv, TWv)                                                                                         \
+  do {                                                                                                            \
+    if (p.N == 1) BG_TNA1(CKv, TWv, 1);                                                                           \
+    else if (p.N == 2) BG_TNA1(CKv, TWv, 2);                                                                      \
+    else if (p.N == 3) BG_TNA1(CKv, TWv, 3);                                                                      \
+    else BG_TNA1(CKv, TWv, 4);                                                                                    \
+  } while (0)
+#define BG_TNA(CKv)                                                                                               \
+  do {                                                                                                            \
+    if (kThinTW == 16) BG_TNA2(CKv, 16);                                                                          \
+    else BG_TNA2(CKv, 32);                                                                                        \
+  } while (0)
+        snprintf(name, sizeof name, "conv_thin_n_patch_all_%s", tag);
+        dim3 grid((unsigned)bg::cdiv(wamax, kThinTW), (unsigned)bg::cdiv(hamax, kThinTH), (unsigned)p.B);
+        bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
+        if (p.Ck == 16) BG_TNA(16);
+        else if (p.Ck == 32) BG_TNA(32);
+        else BG_TNA(64);
+#undef BG_TNA
+#undef BG_TNA2
+#undef BG_TNA1
+        return L.done(name);
+      }
+    }
     if (lds <= 150 * 1024 && (size_t)p.B * p.nphase <= 65535) {
 #define BG_TNP_ATTR(CKv, TWv) BG_LDS_ATTR_ONCE_V((conv_thin_n_patch_kernel<CKv, TWv>), 150 * 1024)
       BG_TNP_ATTR(16, 32); BG_TNP_ATTR(32, 32); BG_TNP_ATTR(64, 32); BG_TNP_ATTR(16, 16); BG_TNP_ATTR(32, 16); BG_TNP_ATTR(64, 16);
@@ -1310,7 +1534,14 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
       snprintf(name, sizeof name, "conv_thin_k_mfma_%s", tag);
       dim3 grid(tiles_x, tiles_y, p.B * p.nphase);
       bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
-      if (NT == 1) bg::launch(conv_thin_k_mfma_kernel<1>, grid, dim3(256), lds, L.s, p);
+      static const int staged = getenv("BG_THIN_K_STAGED") ? 1 : 0;       // the LDS-staged form (see conv_thin_k_direct_kernel)
+      const size_t a_bytes_k = (size_t)p.B * p.Hs * p.Ws * p.Ck * sizeof(float);
+      if (!staged && a_bytes_k < (1ull << 31) && w_bytes < (1ull << 31)) {
+        p.a_bytes = (unsigned)a_bytes_k;
+        p.w_bytes = (unsigned)w_bytes;
+        if (NT == 1) bg::launch(conv_thin_k_direct_kernel<1>, grid, dim3(256), 0, L.s, p);
+        else bg::launch(conv_thin_k_direct_kernel<2>, grid, dim3(256), 0, L.s, p);
+      } else if (NT == 1) bg::launch(conv_thin_k_mfma_kernel<1>, grid, dim3(256), lds, L.s, p);
       else bg::launch(conv_thin_k_mfma_kernel<2>, grid, dim3(256), lds, L.s, p);
       return L.done(name);
     }

@@ -349,13 +349,10 @@ __global__ __launch_bounds__(256) void conv_rows_gather_kernel(const RowGParams 
   const int RL = p.Wi * Ct;                                  // floats per input row
   if ((RL & 3) == 0) {
     const int q4 = RS / 4;                                   // float4 per LDS row (halo 16 and RL are multiples of 4)
-    for (int idx = tid; idx < nrows_in * q4; idx += 256) {
-      const int r = idx / q4, c4 = idx - r * q4;
+    bg::stage_rows_f4<4>(xl, nrows_in, q4, RS, tid, [&](int r, int c4) -> const float* {
       const int iy = oy0 * st - p.pt + r, e = c4 * 4 - kRgHalo;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if ((unsigned)iy < (unsigned)p.Hi && (unsigned)e < (unsigned)RL) v = *reinterpret_cast<const float4*>(p.A + ((size_t)b * p.Hi + iy) * RL + e);
-      *reinterpret_cast<float4*>(xl + (size_t)r * RS + c4 * 4) = v;
-    }
+      return ((unsigned)iy < (unsigned)p.Hi && (unsigned)e < (unsigned)RL) ? p.A + ((size_t)b * p.Hi + iy) * RL + e : nullptr;
+    });
   } else {
     for (int idx = tid; idx < nrows_in * RS; idx += 256) {
       const int r = idx / RS, c = idx - r * RS;

@@ -861,13 +861,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_co_kernel(const WgradPara
     // dy rows y0 - pt .. y0 + kTcRows - 1 + (K - 1 - pt), zero outside the image, zero halos
     if (((W * Co) & 3) == 0) {                                // float4-addressable rows (see conv_wgrad_thin_ci_kernel)
       const int q4 = RS / 4;
-      for (int idx = tid; idx < nrows * q4; idx += 256) {
-        const int r = idx / q4, c4 = idx - r * q4;
+      bg::stage_rows_f4<4>(tc_lds, nrows, q4, RS, tid, [&](int r, int c4) -> const float* {
         const int oy = y0 - (K - 1 - p.pt) + r, e = c4 * 4 - kTcHalo;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)oy < (unsigned)p.Ho && (unsigned)e < (unsigned)(W * Co)) v = *reinterpret_cast<const float4*>(p.DY + ((size_t)b * p.Ho + oy) * W * Co + e);
-        *reinterpret_cast<float4*>(tc_lds + (size_t)r * RS + c4 * 4) = v;
-      }
+        return ((unsigned)oy < (unsigned)p.Ho && (unsigned)e < (unsigned)(W * Co)) ? p.DY + ((size_t)b * p.Ho + oy) * W * Co + e : nullptr;
+      });
     } else {
       for (int idx = tid; idx < nrows * RS; idx += 256) {
         const int r = idx / RS, c = idx - r * RS;
@@ -975,13 +972,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_thin_ci_kernel(const WgradPara
       // rows are float4-addressable (x is 16-byte aligned, the halo is 16 floats): a quarter of the load instructions of the
       // scalar copy below, which issued 31 dword loads per thread and block on the 128-pixel critic (round 3)
       const int q4 = RS / 4;
-      for (int idx = tid; idx < nrows * q4; idx += 256) {
-        const int r = idx / q4, c4 = idx - r * q4;
+      bg::stage_rows_f4<4>(ti_lds, nrows, q4, RS, tid, [&](int r, int c4) -> const float* {
         const int yy = oy0 * st - p.pt + r, e = c4 * 4 - kTiHalo;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)yy < (unsigned)H && (unsigned)e < (unsigned)(W * Ci)) v = *reinterpret_cast<const float4*>(p.X + ((size_t)b * H + yy) * W * Ci + e);
-        *reinterpret_cast<float4*>(ti_lds + (size_t)r * RS + c4 * 4) = v;
-      }
+        return ((unsigned)yy < (unsigned)H && (unsigned)e < (unsigned)(W * Ci)) ? p.X + ((size_t)b * H + yy) * W * Ci + e : nullptr;
+      });
     } else {
       for (int idx = tid; idx < nrows * RS; idx += 256) {
         const int r = idx / RS, c = idx - r * RS;

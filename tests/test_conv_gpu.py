@@ -19,6 +19,7 @@ CASES = [
     (3, 20, 12, 16, 3, 1), (2, 40, 16, 32, 2, 1),          # thin-Co row kernels: Ci 16 / 32, ragged row blocks
     (3, 24, 24, 1, 64, 2), (2, 18, 16, 3, 16, 1), (2, 36, 32, 2, 32, 2),   # thin-Ci row kernels: Co 64 / 16 / 32, ragged row blocks
     (3, 32, 32, 3, 32, 2), (3, 64, 64, 3, 16, 2), (5, 24, 32, 16, 3, 1), (2, 20, 16, 3, 32, 1), (3, 36, 64, 64, 2, 1),   # scatter-form row kernels (thin-N fwd / dgrad)
+    (3, 27, 25, 1, 64, 2), (2, 44, 40, 2, 16, 2), (5, 13, 14, 4, 32, 2),         # data gradients to 1 / 2 / 4 channels: all phases from one staged patch (odd sizes: phases of different extents; several tiles)
     (2, 20, 128, 16, 3, 1), (2, 24, 256, 3, 16, 2),                           # ... on 128-pixel rows (8 waves per workgroup)
     (128, 4, 4, 64, 64, 1), (128, 8, 8, 32, 64, 2), (128, 8, 8, 64, 32, 2),   # position-major tiles: padding taps skipped (64- and 128-row tiles)
     (1024, 16, 16, 16, 32, 2),                                                 # position-major AND the four phases merged in one workgroup
