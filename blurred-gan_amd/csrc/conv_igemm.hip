@@ -613,13 +613,16 @@ __global__ __launch_bounds__(256) void conv_thin_n_patch_kernel(const GatherPara
 // The same for ALL sub-pixel phases of a transposed conv from ONE staged patch (MNIST's ConvT 64 -> 1 and the data gradient of its
 // Conv 1 -> 64: 14 x 14 anchors, four phases).  The per-phase form above stages the same 14 x 14 x 64 source four times, once per
 // (image, phase) workgroup, each with an 18 x 18 pixel patch of 88 KB -- one workgroup per CU, four rounds at batch 256, 81 us for
-// 13.6 MB of traffic.  Here a workgroup owns an anchor tile of one image, its patch carries the union of the phases' halos and only
-// the rows / columns the map really has (16 x 16 pixels, 70 KB: two workgroups per CU), and every thread walks the phases of its
-// anchor.  Same taps in the same order per output: bit-identical to the per-phase kernel.
+// 13.6 MB of traffic -- and reads its weights with wave-uniform scalar loads INSIDE the channel loop, each waited for before its
+// four FMAs.  Here a workgroup owns 64 anchors of one image (4 x 16 or 2 x 32) and wave w computes phase w of them: four times the
+// workgroups (256 at MNIST's batch of 64: every CU busy), a quarter of the taps per thread, no divergence inside a wave.  The
+// patch carries the union of the phases' halos, clipped to the anchors the map has (6 x 18 pixels, 29 KB); it and the weights of
+// every tap go to LDS in ONE batch of up to eight loads per thread (a load -> LDS write loop is a chain of global round trips).
+// Same taps in the same order per output: bit-identical to the per-phase kernel.
 template <int CK, int kThinTW, int N>
 __global__ __launch_bounds__(256) void conv_thin_n_patch_all_kernel(const GatherParams p, int ha_max, int wa_max, int ntap_w) {
   extern __shared__ __attribute__((aligned(16))) float patch[];
-  constexpr int kThinTH = 256 / kThinTW;
+  constexpr int kThinTH = 64 / kThinTW;
   constexpr int CS = CK + 4, Q = CK / 4;
   const int b = blockIdx.z;
   const int a0 = blockIdx.y * kThinTH, x0 = blockIdx.x * kThinTW;
@@ -637,69 +640,67 @@ __global__ __launch_bounds__(256) void conv_thin_n_patch_all_kernel(const Gather
   const int PW = (tw - 1) * p.ss + (dmax_x - dmin_x) + 1;
   const int sy0 = a0 * p.ss + dmin_y, sx0 = x0 * p.ss + dmin_x;
   const float* src = p.A + (size_t)b * p.Hs * p.Ws * CK;
-  // eight loads in flight per thread: one load -> one LDS write per iteration is a chain of global round trips (16 of them for
-  // a 16 x 16 x 64 patch), which is what a workgroup of this kernel spent most of its time on
+  float* wl = patch + PH * PW * CS;
   constexpr int SU = 8;
-  const int total = PH * PW * Q;
+  const int npatch = PH * PW * Q, total = npatch + ntap_w * N * Q;               // float4 items: the patch, then the weights
   for (int i0 = threadIdx.x; i0 < total; i0 += 256 * SU) {
     float4 v[SU];
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
       const int idx = i0 + u * 256;
-      const int q = idx % Q, pix = idx / Q;
-      const int py = pix / PW, px = pix - py * PW;
-      const int sy = sy0 + py, sx = sx0 + px;
       v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (idx < total && (unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
-        v[u] = *reinterpret_cast<const float4*>(src + ((size_t)sy * p.Ws + sx) * CK + q * 4);
+      if (idx < npatch) {
+        const int q = idx % Q, pix = idx / Q;
+        const int py = pix / PW, px = pix - py * PW;
+        const int sy = sy0 + py, sx = sx0 + px;
+        if ((unsigned)sy < (unsigned)p.Hs && (unsigned)sx < (unsigned)p.Ws)
+          v[u] = *reinterpret_cast<const float4*>(src + ((size_t)sy * p.Ws + sx) * CK + q * 4);
+      } else if (idx < total) {
+        v[u] = *reinterpret_cast<const float4*>(p.Wt + (size_t)(idx - npatch) * 4);
+      }
     }
 #pragma unroll
     for (int u = 0; u < SU; ++u) {
       const int idx = i0 + u * 256;
-      if (idx < total) *reinterpret_cast<float4*>(patch + (idx / Q) * CS + (idx % Q) * 4) = v[u];
+      if (idx < npatch) *reinterpret_cast<float4*>(patch + (idx / Q) * CS + (idx % Q) * 4) = v[u];
+      else if (idx < total) *reinterpret_cast<float4*>(wl + (idx - npatch) * 4) = v[u];
     }
   }
-  // the weights of every tap go to LDS as well: read from global they are wave-uniform scalar loads INSIDE the channel loop, each
-  // waited for before its four FMAs -- 400 dependent round trips per thread, 50 us for a 3 us kernel
-  float* wl = patch + PH * PW * CS;
-  for (int idx = threadIdx.x; idx < ntap_w * N * Q; idx += 256)
-    *reinterpret_cast<float4*>(wl + idx * 4) = *reinterpret_cast<const float4*>(p.Wt + (size_t)idx * 4);
   __syncthreads();
-  const int ty = threadIdx.x / kThinTW, tx = threadIdx.x % kThinTW;
-  if (ty >= th || tx >= tw) return;
-  const float* base = patch + ((ty * p.ss - dmin_y) * PW + tx * p.ss - dmin_x) * CS;
+  const int ph = threadIdx.x >> 6, l = threadIdx.x & 63;                          // wave = phase
+  const int ty = l / kThinTW, tx = l % kThinTW;
+  if (ph >= p.nphase || ty >= th || tx >= tw) return;
+  const GatherPhase& g = p.ph[ph];
   const int a_ = a0 + ty, bx = x0 + tx;
-  for (int ph = 0; ph < p.nphase; ++ph) {
-    const GatherPhase& g = p.ph[ph];
-    if (a_ >= g.Ha || bx >= g.Wa) continue;
-    float acc[N];
+  if (a_ >= g.Ha || bx >= g.Wa) return;
+  const float* base = patch + ((ty * p.ss - dmin_y) * PW + tx * p.ss - dmin_x) * CS;
+  float acc[N];
 #pragma unroll
-    for (int n = 0; n < N; ++n) acc[n] = 0.f;
-    for (int t = 0; t < g.ntaps; ++t) {
-      const int tp = g.tap[t];
-      const float* a = base + (bg::tap_dy(tp) * PW + bg::tap_dx(tp)) * CS;
-      const float* w = wl + bg::tap_wi(tp) * N * CK;                // same address in every lane: LDS broadcast
-      float4 av[Q];                                                 // the pixel's channels at this tap, all reads in flight at once
+  for (int n = 0; n < N; ++n) acc[n] = 0.f;
+  for (int t = 0; t < g.ntaps; ++t) {
+    const int tp = g.tap[t];
+    const float* a = base + (bg::tap_dy(tp) * PW + bg::tap_dx(tp)) * CS;
+    const float* w = wl + bg::tap_wi(tp) * N * CK;                  // same address in every lane: LDS broadcast
+    float4 av[Q];                                                   // the pixel's channels at this tap, all reads in flight at once
 #pragma unroll
-      for (int q = 0; q < Q; ++q) av[q] = *reinterpret_cast<const float4*>(a + q * 4);
+    for (int q = 0; q < Q; ++q) av[q] = *reinterpret_cast<const float4*>(a + q * 4);
 #pragma unroll
-      for (int q = 0; q < Q; ++q) {
+    for (int q = 0; q < Q; ++q) {
 #pragma unroll
-        for (int n = 0; n < N; ++n) {
-          const float4 wv = *reinterpret_cast<const float4*>(w + n * CK + q * 4);
-          acc[n] = fmaf(av[q].x, wv.x, acc[n]);
-          acc[n] = fmaf(av[q].y, wv.y, acc[n]);
-          acc[n] = fmaf(av[q].z, wv.z, acc[n]);
-          acc[n] = fmaf(av[q].w, wv.w, acc[n]);
-        }
+      for (int n = 0; n < N; ++n) {
+        const float4 wv = *reinterpret_cast<const float4*>(w + n * CK + q * 4);
+        acc[n] = fmaf(av[q].x, wv.x, acc[n]);
+        acc[n] = fmaf(av[q].y, wv.y, acc[n]);
+        acc[n] = fmaf(av[q].z, wv.z, acc[n]);
+        acc[n] = fmaf(av[q].w, wv.w, acc[n]);
       }
     }
-    const size_t dst = ((size_t)b * p.Hd + a_ * p.ds + g.py) * p.Wd + bx * p.ds + g.px;
+  }
+  const size_t dst = ((size_t)b * p.Hd + a_ * p.ds + g.py) * p.Wd + bx * p.ds + g.px;
 #pragma unroll
-    for (int n = 0; n < N; ++n) {
-      const size_t idx = dst * N + n;
-      p.C[idx] = bg::apply_epilogue(p, acc[n], idx, n);
-    }
+  for (int n = 0; n < N; ++n) {
+    const size_t idx = dst * N + n;
+    p.C[idx] = bg::apply_epilogue(p, acc[n], idx, n);
   }
 }
 
@@ -1447,7 +1448,8 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     }
     // all phases from one staged patch (transposed convs): union halo, the tile clipped to the anchors the map has
     static const int no_all = getenv("BG_NO_THIN_N_ALL") ? 1 : 0;
-    if (p.nphase > 1 && !no_all && p.B <= 65535) {
+    if (p.nphase > 1 && p.nphase <= 4 && !no_all && p.B <= 65535) {          // one wave per phase, 64 anchors per workgroup
+      const int kAllTH = 64 / kThinTW;
       int mny = 127, mxy = -127, mnx = 127, mxx = -127, hamax = 0, wamax = 0;
       for (int i = 0; i < p.nphase; ++i) {
         hamax = std::max(hamax, p.ph[i].Ha); wamax = std::max(wamax, p.ph[i].Wa);
@@ -1456,7 +1458,7 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
           mny = std::min(mny, dy); mxy = std::max(mxy, dy); mnx = std::min(mnx, dx); mxx = std::max(mxx, dx);
         }
       }
-      const size_t PHu = (size_t)(std::min(kThinTH, hamax) - 1) * p.ss + (mxy - mny) + 1;
+      const size_t PHu = (size_t)(std::min(kAllTH, hamax) - 1) * p.ss + (mxy - mny) + 1;
       const size_t PWu = (size_t)(std::min(kThinTW, wamax) - 1) * p.ss + (mxx - mnx) + 1;
       const size_t lds_all = (PHu * PWu * (size_t)(p.Ck + 4) + (size_t)ntap_w * p.N * p.Ck) * sizeof(float);
       if (lds_all <= 150 * 1024) {
@@ -1478,7 +1480,7 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     else BG_TNA2(CKv, 32);                                                                                        \
   } while (0)
         snprintf(name, sizeof name, "conv_thin_n_patch_all_%s", tag);
-        dim3 grid((unsigned)bg::cdiv(wamax, kThinTW), (unsigned)bg::cdiv(hamax, kThinTH), (unsigned)p.B);
+        dim3 grid((unsigned)bg::cdiv(wamax, kThinTW), (unsigned)bg::cdiv(hamax, kAllTH), (unsigned)p.B);
         bg::Launch L(stream, name, gather_flops(p), gather_bytes(p));
         if (p.Ck == 16) BG_TNA(16);
         else if (p.Ck == 32) BG_TNA(32);
