@@ -354,14 +354,22 @@ def main():
         step()
     dist.barrier()
     torch.cuda.synchronize()
+    # one event per step on the launch stream (a marker packet per 100+ kernel launches): the spread of the per-step times says
+    # whether `value` -- the mean over a region of a few hundred milliseconds -- carries a host hiccup of the shared box
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         step()
+        marks[i + 1].record()
     dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = dist.max_over_ranks(dt)
     value = B * world * args.steps / dt
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    step_ms = {"p10": round(per_step[len(per_step) // 10], 4), "p50": round(per_step[len(per_step) // 2], 4),
+               "p90": round(per_step[(len(per_step) * 9) // 10], 4), "max": round(per_step[-1], 4)} if per_step else None
     dp_evidence = dist.evidence()          # every rank takes part (an all-reduce and an all-gather through the step's communicator)
 
     # ---- per-kernel HIP-event timing on the launch stream (separate, un-timed steps)
@@ -431,6 +439,8 @@ def main():
                "config": {"workload": f"{args.arch} {H}x{W}x{C} batch {B}/GPU, blur sigma {args.sigma} "
                                       f"({ops.blur_policy(float(gan.std), H, W)[2]} taps), D-step+GP+G-step+Adam",
                           "global_batch": B * world, "parallelism": f"dp{world}"}}
+        if step_ms:
+            out["step_ms"] = step_ms       # rank 0's per-step times over the timed region (GPU events): spread, not the metric
         if dp_evidence:
             # the collective layer's own account of the group: peers counted by an all-reduce through the communicator the
             # gradients use, every rank's physical card -- so that an N-GPU line shows N ranks on N distinct devices over RCCL

@@ -194,8 +194,11 @@ __device__ inline void col_reduce(F f, int M, int N, float* partial) {
 
 // Fast path for C a power of two in [4, 1024]: the matrix is swept as a flat float4 stream, so every lane moves
 // 16 B whatever C is; a thread's four channels are fixed ((4*tid) mod C) because 1024 mod C == 0.
-template <int NQ, class F>
-__device__ inline void flat_reduce(F f, int M, int C, float* partial) {
+// The sweep keeps U loads in flight per thread: `ld(q4)` fetches the operands of float4 number q4, `use(v, c4, acc)` adds them --
+// loads of U iterations first, then their adds in the loop's own order (same sums, same bits).  With one load per iteration, each
+// waited for before the next is issued, 512 workgroups of four waves hold 2 MB in flight and the pass ran at 3.6-4.3 TB/s.
+template <int NQ, int U, class L, class F>
+__device__ inline void flat_reduce(L ld, F use, int M, int C, float* partial) {
   __shared__ float4 red[NQ][kT];
   const int rows_per = (M + gridDim.x - 1) / gridDim.x;
   const int r0 = blockIdx.x * rows_per, r1 = min(M, r0 + rows_per);
@@ -206,7 +209,15 @@ __device__ inline void flat_reduce(F f, int M, int C, float* partial) {
   if (r1 > r0) {
     const size_t base4 = (size_t)r0 * G, total4 = (size_t)(r1 - r0) * G;
     const int c4 = (threadIdx.x % G) * 4;
-    for (size_t q4 = threadIdx.x; q4 < total4; q4 += kT) f(base4 + q4, c4, acc);
+    size_t q4 = threadIdx.x;
+    for (; q4 + (size_t)(U - 1) * kT < total4; q4 += (size_t)U * kT) {
+      decltype(ld((size_t)0)) v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = ld(base4 + q4 + (size_t)u * kT);
+#pragma unroll
+      for (int u = 0; u < U; ++u) use(v[u], c4, acc);
+    }
+    for (; q4 < total4; q4 += kT) use(ld(base4 + q4), c4, acc);
   }
 #pragma unroll
   for (int q = 0; q < NQ; ++q) red[q][threadIdx.x] = acc[q];
@@ -231,16 +242,14 @@ inline int flat_blocks(int M, int C) {
 }
 
 __global__ __launch_bounds__(kT) void colsum_flat_kernel(const float* __restrict__ x, int M, int C, int square, float* partial) {
-  flat_reduce<1>([&](size_t q4, int, float4* a) {
-    const float4 v = reinterpret_cast<const float4*>(x)[q4];
+  flat_reduce<1, 8>([&](size_t q4) { return reinterpret_cast<const float4*>(x)[q4]; }, [&](const float4& v, int, float4* a) {
     if (square) { a[0].x = fmaf(v.x, v.x, a[0].x); a[0].y = fmaf(v.y, v.y, a[0].y); a[0].z = fmaf(v.z, v.z, a[0].z); a[0].w = fmaf(v.w, v.w, a[0].w); }
     else { a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w; }
   }, M, C, partial);
 }
 
 __global__ __launch_bounds__(kT) void bn_stats_flat_kernel(const float* __restrict__ x, int M, int C, float* partial) {
-  flat_reduce<2>([&](size_t q4, int, float4* a) {
-    const float4 v = reinterpret_cast<const float4*>(x)[q4];
+  flat_reduce<2, 8>([&](size_t q4) { return reinterpret_cast<const float4*>(x)[q4]; }, [&](const float4& v, int, float4* a) {
     a[0].x += v.x; a[0].y += v.y; a[0].z += v.z; a[0].w += v.w;
     a[1].x = fmaf(v.x, v.x, a[1].x); a[1].y = fmaf(v.y, v.y, a[1].y); a[1].z = fmaf(v.z, v.z, a[1].z); a[1].w = fmaf(v.w, v.w, a[1].w);
   }, M, C, partial);
@@ -255,13 +264,18 @@ __global__ __launch_bounds__(kT) void bn_bwd_flat_kernel(const float* __restrict
                                                          const float* __restrict__ x, int M, int C, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ mean,
                                                          const float* __restrict__ inv, float alpha, float* partial) {
-  flat_reduce<2>([&](size_t q4, int c4, float4* a) {
-    const float4 d = reinterpret_cast<const float4*>(dy)[q4], xx = reinterpret_cast<const float4*>(x)[q4];
+  struct Ops { float4 d, xx, yy; };
+  flat_reduce<2, 4>([&](size_t q4) {
+    Ops o;
+    o.d = reinterpret_cast<const float4*>(dy)[q4];
+    o.xx = reinterpret_cast<const float4*>(x)[q4];
+    o.yy = y ? reinterpret_cast<const float4*>(y)[q4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    return o;
+  }, [&](const Ops& o, int c4, float4* a) {
+    const float4 d = o.d, xx = o.xx;
     const float4 mu = *reinterpret_cast<const float4*>(mean + c4), iv = *reinterpret_cast<const float4*>(inv + c4);
-    float4 yy;
-    if (y) {
-      yy = reinterpret_cast<const float4*>(y)[q4];
-    } else {
+    float4 yy = o.yy;
+    if (!y) {
       const float4 g = make_float4(gamma[c4], gamma[c4 + 1], gamma[c4 + 2], gamma[c4 + 3]);
       const float4 bt = make_float4(beta[c4], beta[c4 + 1], beta[c4 + 2], beta[c4 + 3]);
       yy.x = bn_pre_act(xx.x, g.x, mu.x, iv.x, bt.x); yy.y = bn_pre_act(xx.y, g.y, mu.y, iv.y, bt.y);
