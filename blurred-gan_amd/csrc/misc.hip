@@ -238,7 +238,8 @@ __device__ inline void flat_reduce(L ld, F use, int M, int C, float* partial) {
 inline bool flat_ok(int M, int C) { return C >= 4 && C <= 1024 && (C & (C - 1)) == 0 && M >= 64; }
 inline int flat_blocks(int M, int C) {
   const size_t total4 = (size_t)M * C / 4;
-  return (int)std::max<size_t>(1, std::min<size_t>({(size_t)512, total4 / (kT * 8), (size_t)M}));
+  static const size_t cap = getenv("BG_FLAT_BLOCKS") ? (size_t)atoi(getenv("BG_FLAT_BLOCKS")) : 512;
+  return (int)std::max<size_t>(1, std::min<size_t>({cap, total4 / (kT * 8), (size_t)M}));
 }
 
 __global__ __launch_bounds__(kT) void colsum_flat_kernel(const float* __restrict__ x, int M, int C, int square, float* partial) {
@@ -452,19 +453,39 @@ __global__ __launch_bounds__(kT) void bn_apply_kernel(const float* __restrict__ 
   if ((C & 3) == 0 && ptr_al16(x) && ptr_al16(y) && total <= 0xffffffffull) {
     const bool pa = ptr_al16(gamma) && ptr_al16(beta) && ptr_al16(mean) && ptr_al16(inv_or_var);
     const unsigned total4 = (unsigned)(total >> 2);
-    for (unsigned q = blockIdx.x * kT + threadIdx.x; q < total4; q += gridDim.x * kT) {
-      const unsigned e = q * 4u;
-      const int c = (int)(e % (unsigned)C);
-      const float4 xv = *reinterpret_cast<const float4*>(x + e);
-      const float4 g = load4_param(gamma, c, pa), bt = load4_param(beta, c, pa), m = load4_param(mean, c, pa);
-      float4 iv = load4_param(inv_or_var, c, pa);
-      if (is_var) { iv.x = 1.0f / sqrtf(iv.x + eps); iv.y = 1.0f / sqrtf(iv.y + eps); iv.z = 1.0f / sqrtf(iv.z + eps); iv.w = 1.0f / sqrtf(iv.w + eps); }
+    const unsigned stride = gridDim.x * kT;
+    auto one = [&](const float4& xv, const float4& g, const float4& bt, const float4& m, const float4& iv) {
       float4 v;
       v.x = g.x * ((xv.x - m.x) * iv.x) + bt.x; v.y = g.y * ((xv.y - m.y) * iv.y) + bt.y;
       v.z = g.z * ((xv.z - m.z) * iv.z) + bt.z; v.w = g.w * ((xv.w - m.w) * iv.w) + bt.w;
       v.x = v.x > 0.f ? v.x : alpha * v.x; v.y = v.y > 0.f ? v.y : alpha * v.y;
       v.z = v.z > 0.f ? v.z : alpha * v.z; v.w = v.w > 0.f ? v.w : alpha * v.w;
-      *reinterpret_cast<float4*>(y + e) = v;
+      return v;
+    };
+    auto params = [&](int c, float4& g, float4& bt, float4& m, float4& iv) {
+      g = load4_param(gamma, c, pa); bt = load4_param(beta, c, pa); m = load4_param(mean, c, pa);
+      iv = load4_param(inv_or_var, c, pa);
+      if (is_var) { iv.x = 1.0f / sqrtf(iv.x + eps); iv.y = 1.0f / sqrtf(iv.y + eps); iv.z = 1.0f / sqrtf(iv.z + eps); iv.w = 1.0f / sqrtf(iv.w + eps); }
+    };
+    unsigned q = blockIdx.x * kT + threadIdx.x;
+    if ((stride * 4u) % (unsigned)C == 0u) {
+      // a thread meets the same four channels in every iteration: their parameters are read once, and two float4 of the stream
+      // are in flight per thread (the per-iteration form re-read four parameter quads and waited for each before its one store)
+      float4 g, bt, m, iv;
+      params((int)((q * 4u) % (unsigned)C), g, bt, m, iv);
+      for (; q + stride < total4; q += 2 * stride) {
+        const float4 x0 = *reinterpret_cast<const float4*>(x + q * 4u), x1 = *reinterpret_cast<const float4*>(x + (q + stride) * 4u);
+        *reinterpret_cast<float4*>(y + q * 4u) = one(x0, g, bt, m, iv);
+        *reinterpret_cast<float4*>(y + (q + stride) * 4u) = one(x1, g, bt, m, iv);
+      }
+      if (q < total4) *reinterpret_cast<float4*>(y + q * 4u) = one(*reinterpret_cast<const float4*>(x + q * 4u), g, bt, m, iv);
+      return;
+    }
+    for (; q < total4; q += stride) {
+      const unsigned e = q * 4u;
+      float4 g, bt, m, iv;
+      params((int)(e % (unsigned)C), g, bt, m, iv);
+      *reinterpret_cast<float4*>(y + e) = one(*reinterpret_cast<const float4*>(x + e), g, bt, m, iv);
     }
     return;
   }
@@ -510,31 +531,55 @@ __global__ __launch_bounds__(kT) void bn_bwd_apply_kernel(const float* __restric
     const bool pa = ptr_al16(gamma) && ptr_al16(mean) && ptr_al16(inv) && ptr_al16(dgamma) && ptr_al16(dbeta) && ptr_al16(beta);
     const unsigned total4 = (unsigned)(total >> 2);
     const float fM = (float)M;
-    for (unsigned q = blockIdx.x * kT + threadIdx.x; q < total4; q += gridDim.x * kT) {
-      const unsigned e = q * 4u;
-      const int c = (int)(e % (unsigned)C);
-      const float4 dyv = *reinterpret_cast<const float4*>(dy + e);
-      const float4 xv = *reinterpret_cast<const float4*>(x + e);
-      const float4 g = load4_param(gamma, c, pa), m = load4_param(mean, c, pa), iv = load4_param(inv, c, pa);
-      const float4 dg = load4_param(dgamma, c, pa), db = load4_param(dbeta, c, pa);
-      float4 yv;
-      if (y) {
-        yv = *reinterpret_cast<const float4*>(y + e);
-      } else {
-        const float4 bt = load4_param(beta, c, pa);
-        yv.x = bn_pre_act(xv.x, g.x, m.x, iv.x, bt.x); yv.y = bn_pre_act(xv.y, g.y, m.y, iv.y, bt.y);
-        yv.z = bn_pre_act(xv.z, g.z, m.z, iv.z, bt.z); yv.w = bn_pre_act(xv.w, g.w, m.w, iv.w, bt.w);
+    const unsigned stride = gridDim.x * kT;
+    struct P { float4 g, m, iv, dg, db, bt; };
+    auto params = [&](int c) {
+      P p;
+      p.g = load4_param(gamma, c, pa); p.m = load4_param(mean, c, pa); p.iv = load4_param(inv, c, pa);
+      p.dg = load4_param(dgamma, c, pa); p.db = load4_param(dbeta, c, pa);
+      p.bt = y ? make_float4(0.f, 0.f, 0.f, 0.f) : load4_param(beta, c, pa);
+      return p;
+    };
+    auto one = [&](const float4& dyv, const float4& xv, float4 yv, const P& p) {
+      if (!y) {
+        yv.x = bn_pre_act(xv.x, p.g.x, p.m.x, p.iv.x, p.bt.x); yv.y = bn_pre_act(xv.y, p.g.y, p.m.y, p.iv.y, p.bt.y);
+        yv.z = bn_pre_act(xv.z, p.g.z, p.m.z, p.iv.z, p.bt.z); yv.w = bn_pre_act(xv.w, p.g.w, p.m.w, p.iv.w, p.bt.w);
       }
       float4 o;
 #define BG_BN_BWD1(k)                                                   \
   {                                                                     \
     const float dz = dyv.k * (yv.k > 0.f ? 1.f : alpha);                \
-    const float xh = (xv.k - m.k) * iv.k;                               \
-    o.k = g.k * iv.k * invM * (fM * dz - db.k - xh * dg.k);             \
+    const float xh = (xv.k - p.m.k) * p.iv.k;                           \
+    o.k = p.g.k * p.iv.k * invM * (fM * dz - p.db.k - xh * p.dg.k);     \
   }
       BG_BN_BWD1(x) BG_BN_BWD1(y) BG_BN_BWD1(z) BG_BN_BWD1(w)
 #undef BG_BN_BWD1
-      *reinterpret_cast<float4*>(dx + e) = o;
+      return o;
+    };
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    unsigned q = blockIdx.x * kT + threadIdx.x;
+    if ((stride * 4u) % (unsigned)C == 0u) {       // fixed channels per thread: parameters once, two stream quads in flight (see bn_apply_kernel)
+      const P p = params((int)((q * 4u) % (unsigned)C));
+      for (; q + stride < total4; q += 2 * stride) {
+        const unsigned e0 = q * 4u, e1 = (q + stride) * 4u;
+        const float4 d0 = *reinterpret_cast<const float4*>(dy + e0), d1 = *reinterpret_cast<const float4*>(dy + e1);
+        const float4 x0 = *reinterpret_cast<const float4*>(x + e0), x1 = *reinterpret_cast<const float4*>(x + e1);
+        const float4 y0 = y ? *reinterpret_cast<const float4*>(y + e0) : z4, y1 = y ? *reinterpret_cast<const float4*>(y + e1) : z4;
+        *reinterpret_cast<float4*>(dx + e0) = one(d0, x0, y0, p);
+        *reinterpret_cast<float4*>(dx + e1) = one(d1, x1, y1, p);
+      }
+      if (q < total4) {
+        const unsigned e = q * 4u;
+        *reinterpret_cast<float4*>(dx + e) = one(*reinterpret_cast<const float4*>(dy + e), *reinterpret_cast<const float4*>(x + e),
+                                                 y ? *reinterpret_cast<const float4*>(y + e) : z4, p);
+      }
+      return;
+    }
+    for (; q < total4; q += stride) {
+      const unsigned e = q * 4u;
+      const P p = params((int)(e % (unsigned)C));
+      *reinterpret_cast<float4*>(dx + e) = one(*reinterpret_cast<const float4*>(dy + e), *reinterpret_cast<const float4*>(x + e),
+                                               y ? *reinterpret_cast<const float4*>(y + e) : z4, p);
     }
     return;
   }
