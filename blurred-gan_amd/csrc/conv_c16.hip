@@ -55,9 +55,19 @@ __global__ __launch_bounds__(256) void conv_c16_dgrad_kernel(const C16Params p) 
 
   const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.A), 0, (int)p.a_bytes, 0x00020000);
   // weights -> LDS (once per workgroup); halo columns of both row buffers -> 0 (never written again)
-  for (int i = tid; i < 25 * 16 * (kDgCk / 4); i += 256) {
-    const int r = i >> 3, q = i & 7;
-    *reinterpret_cast<float4*>(wl + r * kDgAst + q * 4) = *reinterpret_cast<const float4*>(p.Wt + (size_t)r * kDgCk + q * 4);
+  {                                                           // 3200 float4 = 12.5 per thread: all requested before the first LDS write
+    constexpr int NW = (25 * 16 * (kDgCk / 4) + 255) / 256;
+    float4 wv[NW];
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int i = tid + u * 256, r = i >> 3, q = i & 7;
+      wv[u] = i < 25 * 16 * (kDgCk / 4) ? *reinterpret_cast<const float4*>(p.Wt + (size_t)r * kDgCk + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < NW; ++u) {
+      const int i = tid + u * 256, r = i >> 3, q = i & 7;
+      if (i < 25 * 16 * (kDgCk / 4)) *reinterpret_cast<float4*>(wl + r * kDgAst + q * 4) = wv[u];
+    }
   }
   for (int i = tid; i < 2 * kDgRows * 2 * kDgAst; i += 256) {
     const int e = i % kDgAst, side = (i / kDgAst) & 1, r = i / (2 * kDgAst);

@@ -1081,9 +1081,23 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce_kernel(const GatherPa
   for (unsigned q = blockIdx.x * 256u + threadIdx.x; q < total4; q += gridDim.x * 256u) {
     const unsigned e = q * 4u;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int z = 0; z < p.ksplit; ++z) {
-      const float4 v = *reinterpret_cast<const float4*>(p.slab + (size_t)z * total + e);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    // the slabs of an element four at a time (added in slab order, as before): one load per iteration, waited for before the
+    // next, made this 5 us launch a chain of ksplit global round trips
+    int z = 0;
+    for (; z + 4 <= p.ksplit; z += 4) {
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(p.slab + (size_t)(z + i) * total + e);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+    }
+    if (z < p.ksplit) {
+      float4 v[3];
+#pragma unroll
+      for (int i = 0; i < 3; ++i) v[i] = z + i < p.ksplit ? *reinterpret_cast<const float4*>(p.slab + (size_t)(z + i) * total + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 3; ++i)
+        if (z + i < p.ksplit) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
     }
     const unsigned n = e % (unsigned)p.N;
     float4 b4 = make_float4(0.f, 0.f, 0.f, 0.f), m4 = make_float4(1.f, 1.f, 1.f, 1.f);

@@ -1432,9 +1432,22 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   const int e = (blockIdx.x * 64 + lane) * 4;             // n is a multiple of 4 on this path, slabs 16-B aligned
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   if (e < n) {
-    for (int z = zg; z < ksplit; z += 4) {
-      const float4 v = *reinterpret_cast<const float4*>(slabs + (size_t)z * n + e);
-      s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    int z = zg;                                                // this lane group's slabs zg, zg + 4, ...: four loads in flight, added in order
+    for (; z + 12 < ksplit; z += 16) {
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const float4*>(slabs + (size_t)(z + 4 * i) * n + e);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
+    }
+    {
+      float4 v[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        v[i] = z + 4 * i < ksplit ? *reinterpret_cast<const float4*>(slabs + (size_t)(z + 4 * i) * n + e) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        if (z + 4 * i < ksplit) { s.x += v[i].x; s.y += v[i].y; s.z += v[i].z; s.w += v[i].w; }
     }
   }
   red[zg][lane] = s;

@@ -305,7 +305,14 @@ __device__ inline float wave_sum_partials(const float* __restrict__ partial, int
 #pragma unroll
     for (int i = 0; i < 8; ++i) s += v[i];
   }
-  for (; b < nblk; b += 64, p += step) s += *p;
+  if (b < nblk) {                               // the last, partial batch (all of it when nblk < 512): predicated, still one wait
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = b + i * 64 < nblk ? p[i * step] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+      if (b + i * 64 < nblk) s += v[i];
+  }
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   return __shfl(s, 0, 64);
 }
