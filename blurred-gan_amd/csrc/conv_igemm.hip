@@ -1220,10 +1220,14 @@ double gather_exec_flops(const GatherParams& p, int BM, int BN) {
 }
 
 // split-K plan for small-M layers: fewer than 2 workgroups per CU and a long contraction
-int plan_splitk(const GatherParams& p, int bm, int bn, int bk) {
+int plan_splitk(const GatherParams& p, int bm, int bn, int /*bk*/) {
   const long wgs = (long)bg::cdiv(max_phase_m(p), bm) * bg::cdiv(p.N, bn) * p.nphase;
+  // the K loop's length in the units the thresholds below were tuned in (steps of 32 channels; of 16 where 32 does not divide the
+  // channel count) -- NOT in the launch's own BK: the plan, and with it the workspace bg_conv2d_splitk_workspace_bytes asks for,
+  // must not depend on which K step the dispatcher picks for the layer
+  const int plan_bk = p.Ck % 32 == 0 ? 32 : 16;
   int min_steps = 1 << 30;
-  for (int i = 0; i < p.nphase; ++i) min_steps = std::min(min_steps, p.ph[i].ntaps * (p.Ck / bk));
+  for (int i = 0; i < p.nphase; ++i) min_steps = std::min(min_steps, p.ph[i].ntaps * (p.Ck / plan_bk));
   static const int min_wgs = getenv("BG_SPLITK_MIN_WGS") ? atoi(getenv("BG_SPLITK_MIN_WGS")) : 512;
   static const int tgt_wgs = getenv("BG_SPLITK_TARGET") ? atoi(getenv("BG_SPLITK_TARGET")) : 768;
   static const int force_ks = getenv("BG_SPLITK_FORCE") ? atoi(getenv("BG_SPLITK_FORCE")) : 0;   // tuning aid
@@ -1422,8 +1426,12 @@ int run_gather(GatherParams& p, const bg_epilogue* epi, void* stream, const char
     p.a_bytes = (unsigned)a_bytes;
     p.w_bytes = (unsigned)w_bytes;
     snprintf(name, sizeof name, "conv_igemm_%s", tag);
-    static const int force_bk = getenv("BG_IGEMM_BK") ? atoi(getenv("BG_IGEMM_BK")) : 0;   // tuning aid
-    return (p.Ck % 32 == 0 && force_bk != 16) ? dispatch_igemm<32>(p, epi, stream, name) : dispatch_igemm<16>(p, epi, stream, name);
+    static const int force_bk = getenv("BG_IGEMM_BK") ? atoi(getenv("BG_IGEMM_BK")) : 0;   // tuning aid: 16 / 32 for every layer
+    // K steps of 16 channels for the layers with 32 or 64 channels per tap (measured per layer on the VALU-lean loader, round 5:
+    // 92 / 120 registers and half the LDS put a fifth workgroup on the CU for the 64 x 64 tile and a fourth for the 128 x 32 tile --
+    // D2 fwd -4 %, D2 dgrad -10 %, G5 fwd -6 %, G5 dgrad -3 %; from 128 channels per tap on it is level, from 256 on 2-4 % slower)
+    const bool bk32 = p.Ck % 32 == 0 && (force_bk == 32 || (force_bk != 16 && p.Ck > 64));
+    return bk32 ? dispatch_igemm<32>(p, epi, stream, name) : dispatch_igemm<16>(p, epi, stream, name);
   }
   if (p.nphase == 1 && p.ss == 1 && p.ds == 1 && p.Ck % 4 == 0 && p.Ck >= 16 && p.B <= 65535) {
     // full k x k tap rectangle of a stride-1 forward conv with N*k <= 16 -> MFMA thin-N kernel
