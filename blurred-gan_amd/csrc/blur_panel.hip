@@ -86,14 +86,19 @@ __global__ __launch_bounds__(512) void blur_panel_kernel(const PanelParams p) {
     const __amdgpu_buffer_rsrc_t rs =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x + (size_t)img * H * Q), 0, H * Q * 4, 0x00020000);
     // lane (li, kk): row k0 + 2s + kk, floats 3 * (32 * wave + li) .. + 2;  rows >= H lie past the descriptor's range: zeros
-    unsigned off = (unsigned)(((k0 + kk) * W + 32 * wave + li) * 12);
-    const unsigned dstep = (unsigned)(2 * W * 12);
+    // the lane's part of the offset stays in a register for the whole pass; the k-pair's part (2 rows per pair) travels in the buffer
+    // instruction's SCALAR offset, which the range check includes (tools/probes/buffer_soffset_range.hip: voffset + soffset >=
+    // num_records reads zeros) -- the pass had one v_add per load and eight more per group of eight (17 vector instructions per 24
+    // MFMAs; on gfx950 every one of them is matrix time, profiles/r05_a_gather_gemm_limits.md section 11)
+    const unsigned off = (unsigned)(((k0 + kk) * W + 32 * wave + li) * 12);
+    const int dstep = 2 * W * 12;
+    int soff = 0;
     const float* ta = tz + kPad + half + k0 + kk - r0 - li;            // + 2s
     floatx3 pf[kDepth];
 #pragma unroll
     for (int j = 0; j < kDepth; ++j) {
-      pf[j] = __builtin_bit_cast(floatx3, __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0));
-      off += dstep;
+      pf[j] = __builtin_bit_cast(floatx3, __builtin_amdgcn_raw_buffer_load_b96(rs, off, soff, 0));
+      soff += dstep;
     }
     // the tap table goes up while the first eight loads are in flight
     for (int j = tid; j < T + 2 * kPad; j += blockDim.x) tz[j] = (j >= kPad && j < kPad + T) ? p.taps[j - kPad] : 0.f;
@@ -110,9 +115,9 @@ __global__ __launch_bounds__(512) void blur_panel_kernel(const PanelParams p) {
         acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.y, acc[1], 0, 0, 0);
         acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b.z, acc[2], 0, 0, 0);
 #if !(defined(BG_DIAG) && defined(PANEL_NO_LOADS))
-        pf[j] = __builtin_bit_cast(floatx3, __builtin_amdgcn_raw_buffer_load_b96(rs, off, 0, 0));
+        pf[j] = __builtin_bit_cast(floatx3, __builtin_amdgcn_raw_buffer_load_b96(rs, off, soff, 0));
 #endif
-        off += dstep;
+        soff += dstep;
         __builtin_amdgcn_sched_barrier(0);
       }
     }
