@@ -151,6 +151,37 @@ __global__ __launch_bounds__(512) void blur_panel_kernel(const PanelParams p) {
     // 34 us for the 26 us of MFMAs this pass issues at the clock it runs at)
     float aA = ta[0], bA0 = yb[0], bA1 = yb[1], bA2 = yb[2], aB = 0.f, bB0 = 0.f, bB1 = 0.f, bB2 = 0.f;
     int s = 0;
+    // four k-pairs per trip while they last (the pointer bumps and the tail select are vector instructions: two trips' worth per 12
+    // MFMAs instead of per 6), then the two-pair loop below takes what is left with the same register protocol
+    for (; s + 4 <= K2; s += 4) {
+      aB = ta[2]; bB0 = yb[6]; bB1 = yb[7]; bB2 = yb[8];                 // pair s + 1
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA2, acc[2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      aA = ta[4]; bA0 = yb[12]; bA1 = yb[13]; bA2 = yb[14];              // pair s + 2
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB, bB0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB, bB1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB, bB2, acc[2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      aB = ta[6]; bB0 = yb[18]; bB1 = yb[19]; bB2 = yb[20];              // pair s + 3 (exists: s + 4 <= K2)
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aA, bA2, acc[2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int adv4 = s + 4 < K2 ? 24 : 18;                             // pair s + 4, or pair s + 3 again when it is the last
+      aA = ta[8]; bA0 = yb[adv4]; bA1 = yb[adv4 + 1]; bA2 = yb[adv4 + 2];
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB, bB0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB, bB1, acc[1], 0, 0, 0);
+      acc[2] = __builtin_amdgcn_mfma_f32_32x32x2f32(aB, bB2, acc[2], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      ta += 8;
+      yb += 24;
+    }
     for (; s + 2 <= K2; s += 2) {
       aB = ta[2]; bB0 = yb[6]; bB1 = yb[7]; bB2 = yb[8];                 // pair s + 1 (exists: s + 2 <= K2)
       __builtin_amdgcn_sched_barrier(0);
