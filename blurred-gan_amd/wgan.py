@@ -24,7 +24,7 @@ from .utils import JsonSerializable, ParseableFromCommandLine
 ADAM_B1, ADAM_B2, ADAM_EPS = 0.9, 0.999, 1e-7       # tf.keras.optimizers.Adam defaults (wgan.py:56)
 
 
-_KEY_ENV = ("BGAN_NO_FUSED_BLUR3", "BGAN_NO_FOLD_MANY", "BGAN_NO_FUSED_BN_STATS", "BG_BLUR_NO_ROWS", "BG_BLUR_NO_PANEL", "BG_WGRAD_NO_STRIP")
+_KEY_ENV = ("BGAN_NO_FUSED_BLUR3", "BGAN_NO_FOLD_MANY", "BGAN_NO_FUSED_BN_STATS", "BG_BLUR_NO_ROWS", "BG_BLUR_NO_PANEL", "BG_BLUR_PANEL16", "BG_WGRAD_NO_STRIP")
 
 
 def _env_switches():
