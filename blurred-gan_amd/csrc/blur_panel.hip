@@ -437,12 +437,15 @@ static size_t panel16_lds_bytes(int W, int n_taps) {
 }
 // 16-row panels (two workgroups per CU): BG_BLUR_PANEL16=0 keeps the 32-row kernel.  Twice the panels read 1.8x the rows through
 // L2 in pass 1 (16 x (16 + T - 1) against 8 x (32 + T - 1) per 256-row image), and from about 200 taps on that costs what the
-// shorter band saves: 64 x 256x256x3 at 73 / 101 / 143 / 163 / 203 / 255 taps: -7.6 / -5.5 / -1.8 / -2.5 / 0 / +1 % (same box,
-// gpurun_out/r05_aj); 128- and 192-pixel images -3 ... -6 %.
+// shorter band saves: 64 x 256x256x3 at 73 / 101 / 143 / 163 / 203 / 223 / 255 taps: -7.6 / -5.5 / -1.8 / -2.5 / 0 / +3 / +1 % (same
+// box, gpurun_out/r05_aj, r05_ak); 128- and 192-pixel images -3 ... -6 %.  (A third form -- 32-row panels on 16x16x4 tiles whose two
+// row halves contract over their own bands, operand quads in groups of four with a wave-uniform kind per group: the shorter band
+// WITHOUT the extra L2 traffic -- was built, passed every parity case and ran 3-6 % SLOWER than the 32x32x2 kernel at one
+// workgroup per CU (r05_ak): what the 16-row kernel gains it gains through its second resident workgroup.  Removed.)
 static bool panel16_on(int H, int n_taps) {
   const char* e = getenv("BG_BLUR_PANEL16");                      // test aid, read per call (part of the step-program key, wgan.py)
   const int sw = e ? atoi(e) : 1;
-  static const int max_taps = getenv("BG_BLUR_PANEL16_MAX_TAPS") ? atoi(getenv("BG_BLUR_PANEL16_MAX_TAPS")) : 224;
+  static const int max_taps = getenv("BG_BLUR_PANEL16_MAX_TAPS") ? atoi(getenv("BG_BLUR_PANEL16_MAX_TAPS")) : 208;
   return sw != 0 && n_taps <= max_taps && H % 16 == 0 && H / 16 <= 32;
 }
 

@@ -79,7 +79,7 @@ def test_small_image_kernels_row_blocks_and_whole_image(shape, std, monkeypatch)
                                        ((2, 256, 256, 3), 23.5), ((2, 256, 256, 3), 42.34), ((1, 512, 64, 3), 20.0), ((4, 128, 128, 3), 11.2),
                                        ((8, 96, 128, 3), 12.0), ((16, 160, 96, 3), 14.0), ((40, 96, 96, 3), 12.0)])
 def test_wide_tap_panel_kernel(shape, std, monkeypatch):
-    """blur_panel16_kernel / blur_panel_kernel (> 65 taps, RGB, 16-row panels up to 224 taps and 32-row panels beyond or with
+    """blur_panel16_kernel / blur_panel_kernel (> 65 taps, RGB, 16-row panels up to 208 taps and 32-row panels beyond or with
     BG_BLUR_PANEL16=0, both passes in one launch, the pass-1 result in LDS): odd and even panel counts, non-square images, panels whose band is clipped on one side / both sides / not at all, bands wider than the image,
     batches that are multiples of 8 (the XCD-aware placement, with and without its reversed image groups) --
     against the float64 oracle, and against the two-launch band passes it replaces (BG_BLUR_NO_PANEL=1)."""
